@@ -1,0 +1,303 @@
+"""Weight manifests and loaders for the DepthCrafter components.
+
+The manifests enumerate every tensor (diffusers / transformers state-dict name -> shape) the
+HIP engine binds.  They are the enforcement point for the "uncertainty register" of
+SURVEY.md 8(c'): loading real safetensors hard-fails on any missing, unexpected or
+mis-shaped tensor, so a wrong architectural restatement cannot load silently.
+
+Reference: weights are loaded by ``from_pretrained`` at /root/reference/model/depthcrafter.py:18-29
+(``unet_path`` = DepthCrafter UNet dir, ``pre_train_path`` = stable-video-diffusion-img2vid-xt dir,
+fp16 variant).
+"""
+import json
+import os
+from collections import OrderedDict
+from dataclasses import dataclass, field, asdict
+from typing import Dict, Tuple
+
+import numpy as np
+
+
+@dataclass
+class UNetCfg:
+    in_channels: int = 8
+    out_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    layers_per_block: int = 2
+    num_attention_heads: Tuple[int, ...] = (5, 10, 20, 20)
+    cross_attention_dim: int = 1024
+    addition_time_embed_dim: int = 256
+    projection_class_embeddings_input_dim: int = 768
+    norm_groups: int = 32
+    down_has_attn: Tuple[bool, ...] = (True, True, True, False)
+    eps_cross_attn_blocks: float = 1e-6
+    eps_plain_down_block: float = 1e-5
+    eps_mid_block: float = 1e-5
+    eps_up_blocks: float = 1e-6
+
+
+@dataclass
+class VAECfg:
+    in_channels: int = 3
+    out_channels: int = 3
+    latent_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (128, 256, 512, 512)
+    layers_per_block: int = 2
+    norm_groups: int = 32
+    scaling_factor: float = 0.18215
+
+
+@dataclass
+class CLIPCfg:
+    hidden_size: int = 1280
+    intermediate_size: int = 5120
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 16
+    image_size: int = 224
+    patch_size: int = 14
+    projection_dim: int = 1024
+    layer_norm_eps: float = 1e-5
+
+
+def tiny_cfgs():
+    """Small configuration with the full topology, for parity tests that the CPU oracle
+    finishes in seconds."""
+    u = UNetCfg(block_out_channels=(64, 128, 128, 128), num_attention_heads=(1, 2, 2, 2),
+                cross_attention_dim=48, addition_time_embed_dim=16,
+                projection_class_embeddings_input_dim=48, norm_groups=16)
+    v = VAECfg(block_out_channels=(32, 64, 64, 64), norm_groups=8)
+    c = CLIPCfg(hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+                num_attention_heads=2, image_size=224, patch_size=14, projection_dim=48)
+    return u, v, c
+
+
+class _M(OrderedDict):
+    def lin(self, p, cin, cout, bias=True):
+        self[p + ".weight"] = (cout, cin)
+        if bias:
+            self[p + ".bias"] = (cout,)
+
+    def norm(self, p, c):
+        self[p + ".weight"] = (c,)
+        self[p + ".bias"] = (c,)
+
+    def conv2(self, p, cin, cout, k=3, bias=True):
+        self[p + ".weight"] = (cout, cin, k, k)
+        if bias:
+            self[p + ".bias"] = (cout,)
+
+    def conv3(self, p, cin, cout):
+        self[p + ".weight"] = (cout, cin, 3, 1, 1)
+        self[p + ".bias"] = (cout,)
+
+
+def _st_res(m, p, cin, cout, temb):
+    s, t = p + ".spatial_res_block", p + ".temporal_res_block"
+    m.norm(s + ".norm1", cin); m.conv2(s + ".conv1", cin, cout)
+    if temb:
+        m.lin(s + ".time_emb_proj", temb, cout)
+    m.norm(s + ".norm2", cout); m.conv2(s + ".conv2", cout, cout)
+    if cin != cout:
+        m.conv2(s + ".conv_shortcut", cin, cout, k=1)
+    m.norm(t + ".norm1", cout); m.conv3(t + ".conv1", cout, cout)
+    if temb:
+        m.lin(t + ".time_emb_proj", temb, cout)
+    m.norm(t + ".norm2", cout); m.conv3(t + ".conv2", cout, cout)
+    m[p + ".time_mixer.mix_factor"] = (1,)
+
+
+def _attn(m, p, dim, inner, cross=None, bias=False):
+    m.lin(p + ".to_q", dim, inner, bias)
+    m.lin(p + ".to_k", cross or dim, inner, bias)
+    m.lin(p + ".to_v", cross or dim, inner, bias)
+    m.lin(p + ".to_out.0", inner, dim, True)
+
+
+def _ff(m, p, dim, dout=None):
+    m.lin(p + ".net.0.proj", dim, dim * 8)
+    m.lin(p + ".net.2", dim * 4, dout or dim)
+
+
+def _transformer(m, p, ch, cross):
+    m.norm(p + ".norm", ch); m.lin(p + ".proj_in", ch, ch)
+    b = p + ".transformer_blocks.0"
+    m.norm(b + ".norm1", ch); _attn(m, b + ".attn1", ch, ch)
+    m.norm(b + ".norm2", ch); _attn(m, b + ".attn2", ch, ch, cross)
+    m.norm(b + ".norm3", ch); _ff(m, b + ".ff", ch)
+    t = p + ".temporal_transformer_blocks.0"
+    m.norm(t + ".norm_in", ch); _ff(m, t + ".ff_in", ch)
+    m.norm(t + ".norm1", ch); _attn(m, t + ".attn1", ch, ch)
+    m.norm(t + ".norm2", ch); _attn(m, t + ".attn2", ch, ch, cross)
+    m.norm(t + ".norm3", ch); _ff(m, t + ".ff", ch)
+    m.lin(p + ".time_pos_embed.linear_1", ch, ch * 4)
+    m.lin(p + ".time_pos_embed.linear_2", ch * 4, ch)
+    m[p + ".time_mixer.mix_factor"] = (1,)
+    m.lin(p + ".proj_out", ch, ch)
+
+
+def unet_manifest(cfg: UNetCfg = UNetCfg()) -> "OrderedDict[str, tuple]":
+    m = _M()
+    boc = cfg.block_out_channels
+    n, temb, x = len(boc), boc[0] * 4, cfg.cross_attention_dim
+    m.conv2("conv_in", cfg.in_channels, boc[0])
+    m.lin("time_embedding.linear_1", boc[0], temb); m.lin("time_embedding.linear_2", temb, temb)
+    m.lin("add_embedding.linear_1", cfg.projection_class_embeddings_input_dim, temb)
+    m.lin("add_embedding.linear_2", temb, temb)
+    ch = boc[0]
+    for i in range(n):
+        for j in range(cfg.layers_per_block):
+            _st_res(m, f"down_blocks.{i}.resnets.{j}", ch if j == 0 else boc[i], boc[i], temb)
+            if cfg.down_has_attn[i]:
+                _transformer(m, f"down_blocks.{i}.attentions.{j}", boc[i], x)
+        if i != n - 1:
+            m.conv2(f"down_blocks.{i}.downsamplers.0.conv", boc[i], boc[i])
+        ch = boc[i]
+    _st_res(m, "mid_block.resnets.0", boc[-1], boc[-1], temb)
+    _transformer(m, "mid_block.attentions.0", boc[-1], x)
+    _st_res(m, "mid_block.resnets.1", boc[-1], boc[-1], temb)
+    rev, rattn = list(reversed(boc)), list(reversed(cfg.down_has_attn))
+    out = rev[0]
+    L = cfg.layers_per_block + 1
+    for i in range(n):
+        prev, out = out, rev[i]
+        cin = rev[min(i + 1, n - 1)]
+        for j in range(L):
+            skip = cin if j == L - 1 else out
+            rin = prev if j == 0 else out
+            _st_res(m, f"up_blocks.{i}.resnets.{j}", rin + skip, out, temb)
+            if rattn[i]:
+                _transformer(m, f"up_blocks.{i}.attentions.{j}", out, x)
+        if i != n - 1:
+            m.conv2(f"up_blocks.{i}.upsamplers.0.conv", out, out)
+    m.norm("conv_norm_out", boc[0]); m.conv2("conv_out", boc[0], cfg.out_channels)
+    return m
+
+
+def _res2d(m, p, cin, cout):
+    m.norm(p + ".norm1", cin); m.conv2(p + ".conv1", cin, cout)
+    m.norm(p + ".norm2", cout); m.conv2(p + ".conv2", cout, cout)
+    if cin != cout:
+        m.conv2(p + ".conv_shortcut", cin, cout, k=1)
+
+
+def _vae_attn(m, p, ch):
+    m.norm(p + ".group_norm", ch)
+    _attn(m, p, ch, ch, bias=True)
+
+
+def vae_manifest(cfg: VAECfg = VAECfg()) -> "OrderedDict[str, tuple]":
+    m = _M()
+    boc, L = cfg.block_out_channels, cfg.layers_per_block
+    m.conv2("encoder.conv_in", cfg.in_channels, boc[0])
+    ch = boc[0]
+    for i, c in enumerate(boc):
+        for j in range(L):
+            _res2d(m, f"encoder.down_blocks.{i}.resnets.{j}", ch if j == 0 else c, c)
+        if i != len(boc) - 1:
+            m.conv2(f"encoder.down_blocks.{i}.downsamplers.0.conv", c, c)
+        ch = c
+    _res2d(m, "encoder.mid_block.resnets.0", ch, ch)
+    _vae_attn(m, "encoder.mid_block.attentions.0", ch)
+    _res2d(m, "encoder.mid_block.resnets.1", ch, ch)
+    m.norm("encoder.conv_norm_out", ch); m.conv2("encoder.conv_out", ch, 2 * cfg.latent_channels)
+    m.conv2("quant_conv", 2 * cfg.latent_channels, 2 * cfg.latent_channels, k=1)
+    m.conv2("decoder.conv_in", cfg.latent_channels, boc[-1])
+    for j in range(L):
+        _st_res(m, f"decoder.mid_block.resnets.{j}", boc[-1], boc[-1], None)
+    _vae_attn(m, "decoder.mid_block.attentions.0", boc[-1])
+    rev, out = list(reversed(boc)), boc[-1]
+    for i in range(len(boc)):
+        prev, out = out, rev[i]
+        for j in range(L + 1):
+            _st_res(m, f"decoder.up_blocks.{i}.resnets.{j}", prev if j == 0 else out, out, None)
+        if i != len(boc) - 1:
+            m.conv2(f"decoder.up_blocks.{i}.upsamplers.0.conv", out, out)
+    m.norm("decoder.conv_norm_out", boc[0]); m.conv2("decoder.conv_out", boc[0], cfg.out_channels)
+    m.conv3("decoder.time_conv_out", cfg.out_channels, cfg.out_channels)
+    return m
+
+
+def clip_manifest(cfg: CLIPCfg = CLIPCfg()) -> "OrderedDict[str, tuple]":
+    m = _M()
+    d, v = cfg.hidden_size, "vision_model"
+    ntok = (cfg.image_size // cfg.patch_size) ** 2 + 1
+    m[v + ".embeddings.class_embedding"] = (d,)
+    m[v + ".embeddings.patch_embedding.weight"] = (d, 3, cfg.patch_size, cfg.patch_size)
+    m[v + ".embeddings.position_embedding.weight"] = (ntok, d)
+    m.norm(v + ".pre_layrnorm", d)
+    for i in range(cfg.num_hidden_layers):
+        p = f"{v}.encoder.layers.{i}"
+        m.norm(p + ".layer_norm1", d)
+        for nme in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            m.lin(f"{p}.self_attn.{nme}", d, d)
+        m.norm(p + ".layer_norm2", d)
+        m.lin(p + ".mlp.fc1", d, cfg.intermediate_size); m.lin(p + ".mlp.fc2", cfg.intermediate_size, d)
+    m.norm(v + ".post_layernorm", d)
+    m[("visual_projection.weight")] = (cfg.projection_dim, d)
+    return m
+
+
+def random_state(manifest, seed: int, dtype=np.float16) -> Dict[str, np.ndarray]:
+    """Seeded synthetic weights (there are no checkpoints on the build / bench boxes).
+    Linear/conv weights ~ N(0, 1/fan_in) (keeps activations O(1) through the depth so fp16
+    parity tests are meaningful), norm gains ~ 1 + 0.1 N, biases ~ 0.05 N, mixers ~ 0.5 N."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, shape in manifest.items():
+        if name.endswith("mix_factor"):
+            a = rng.normal(0, 0.5, shape)
+        elif len(shape) == 1:
+            is_gain = name.endswith(".weight")
+            a = (1.0 + 0.1 * rng.standard_normal(shape)) if is_gain else 0.05 * rng.standard_normal(shape)
+            if name.endswith("class_embedding"):
+                a = 0.5 * rng.standard_normal(shape)
+        elif "position_embedding" in name:
+            a = 0.1 * rng.standard_normal(shape)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            a = rng.standard_normal(shape, dtype=np.float32) * (1.0 / np.sqrt(fan_in))
+        out[name] = np.ascontiguousarray(a.astype(dtype))
+    return out
+
+
+_IGNORED = ("position_ids",)
+
+
+def check_against_manifest(state: Dict[str, np.ndarray], manifest, what: str):
+    missing = [k for k in manifest if k not in state]
+    extra = [k for k in state if k not in manifest and not k.endswith(_IGNORED)]
+    bad = [(k, tuple(state[k].shape), tuple(manifest[k])) for k in manifest
+           if k in state and tuple(state[k].shape) != tuple(manifest[k])]
+    if missing or extra or bad:
+        raise ValueError(
+            f"{what}: state dict does not match the architecture restated by this build "
+            f"(missing {len(missing)}: {missing[:5]}; unexpected {len(extra)}: {extra[:5]}; "
+            f"shape mismatches {len(bad)}: {bad[:5]})")
+
+
+def load_safetensors(path: str) -> Dict[str, np.ndarray]:
+    from safetensors.numpy import load_file
+    return load_file(path)
+
+
+def _first_existing(d, names):
+    for n in names:
+        p = os.path.join(d, n)
+        if os.path.exists(p):
+            return p
+    raise FileNotFoundError(f"none of {names} under {d}")
+
+
+def load_pretrained(unet_path: str, pre_train_path: str):
+    """diffusers directory layout -> (unet_state, vae_state, clip_state), checked against the
+    manifests.  Raises with a precise diff if the files disagree with the restated architecture."""
+    u = load_safetensors(_first_existing(unet_path, [
+        "diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.fp16.safetensors"]))
+    v = load_safetensors(_first_existing(os.path.join(pre_train_path, "vae"), [
+        "diffusion_pytorch_model.fp16.safetensors", "diffusion_pytorch_model.safetensors"]))
+    c = load_safetensors(_first_existing(os.path.join(pre_train_path, "image_encoder"), [
+        "model.fp16.safetensors", "model.safetensors"]))
+    check_against_manifest(u, unet_manifest(), "UNet")
+    check_against_manifest(v, vae_manifest(), "VAE")
+    check_against_manifest(c, clip_manifest(), "CLIP image encoder")
+    return u, v, c
