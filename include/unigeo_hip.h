@@ -1,0 +1,124 @@
+/* libunigeo_hip.so - C ABI of the MI355X-native (gfx950) DepthCrafter inference path.
+ *
+ * This is the drop-in boundary behind UniGeo's model/ plugin surface.  Each entry point
+ * names the reference interface it replaces (paths relative to the reference checkout).
+ * Plain C types only: no torch / numpy types cross this boundary.
+ *
+ * Conventions
+ *   - every function returning int: 0 = OK, non-zero = error; the message is available from
+ *     ug_last_error(ctx) (the reference raises Python exceptions instead - the ctypes shim in
+ *     unigeo_amd/_lib.py turns a non-zero code back into RuntimeError).
+ *   - the caller owns all host buffers; the library owns all device memory.
+ *   - one context per GPU; calls on a context must be serialised by the caller; the library
+ *     runs on its own HIP stream and synchronises before returning.
+ *   - "video" tensors are channels-last: frames [T,H,W,3] float32 in [0,1] exactly as
+ *     DepthCrafter.prepare_input produces them (model/depthcrafter.py:39-45).
+ *   - noise is an INPUT (the reference draws it from the global CUDA RNG without a generator,
+ *     model/depthcrafter.py:80-90): noise_latents [T,4,H/8,W/8], noise_aug [T,3,H,W], float32,
+ *     laid out as torch.randn would produce them inside the pipeline (NCHW).
+ */
+#ifndef UNIGEO_HIP_H
+#define UNIGEO_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ug_ctx ug_ctx;
+
+enum { UG_DTYPE_F16 = 0, UG_DTYPE_F32 = 1 };
+
+/* Architecture hyper-parameters.  Defaults (ug_*_config_default) are SVD-XT / DepthCrafter:
+ * replaces the config.json files read by from_pretrained (model/depthcrafter.py:18-29). */
+typedef struct {
+  int in_channels, out_channels, num_levels;
+  int block_out_channels[8];
+  int num_attention_heads[8];
+  int down_has_attn[8];
+  int layers_per_block, cross_attention_dim, addition_time_embed_dim, projection_class_embeddings_input_dim;
+  int norm_groups;
+  float eps_cross_attn_blocks, eps_plain_down_block, eps_mid_block, eps_up_blocks;
+} ug_unet_config;
+
+typedef struct {
+  int in_channels, out_channels, latent_channels, num_levels;
+  int block_out_channels[8];
+  int layers_per_block, norm_groups;
+  float scaling_factor;
+} ug_vae_config;
+
+typedef struct {
+  int hidden_size, intermediate_size, num_hidden_layers, num_attention_heads, image_size, patch_size, projection_dim;
+  float layer_norm_eps;
+} ug_clip_config;
+
+void ug_unet_config_default(ug_unet_config* c);
+void ug_vae_config_default(ug_vae_config* c);
+void ug_clip_config_default(ug_clip_config* c);
+
+/* Context: replaces `self.device = cuda:0` + pipeline.to(device) (model/depthcrafter.py:11,31).
+ * workspace_bytes: transient activation arena; persist_bytes: weights in kernel-ready layout. */
+ug_ctx* ug_create(int device_id, size_t workspace_bytes, size_t persist_bytes);
+void ug_destroy(ug_ctx* ctx);
+const char* ug_last_error(ug_ctx* ctx);   /* ctx may be NULL: returns the creation error */
+size_t ug_workspace_peak(ug_ctx* ctx);
+
+/* Weights: replaces DiffusersUNet...from_pretrained / DepthCrafterPipeline.from_pretrained
+ * (model/depthcrafter.py:18-29).  Tensors are uploaded under their diffusers / transformers
+ * state-dict names with a component prefix ("unet.", "vae.", "clip."), then bound; binding
+ * hard-fails on any missing, mis-shaped or unexpected tensor. */
+int ug_load_tensor(ug_ctx* ctx, const char* name, int dtype, int ndim, const int64_t* shape, const void* host_data);
+int ug_bind_unet(ug_ctx* ctx, const ug_unet_config* cfg);
+int ug_bind_vae(ug_ctx* ctx, const ug_vae_config* cfg);
+int ug_bind_clip(ug_ctx* ctx, const ug_clip_config* cfg);
+
+/* The pipeline call: replaces `self.pipeline(frames, height, width, output_type="np",
+ * guidance_scale=1.0, num_inference_steps, window_size=len(frames), overlap, ...).frames[0]`
+ * (model/depthcrafter.py:80-90) plus the wrapper post-processing at :92-97 (depth) and
+ * prepare_output at :48-59 (normals, OpenGL frame).
+ *   ug_dc_set_inputs : host -> HBM (frames, noise, per-frame 3x3 intrinsics or NULL)
+ *   ug_dc_run        : CLIP + VAE-encode + `steps` x (scale, concat, UNet, Euler) + VAE temporal
+ *                      decode (chunks of decode_chunk frames) + depth (+ normals); all on device
+ *   ug_dc_get_outputs: HBM -> host; any pointer may be NULL
+ *                      frames_out [T,H,W,3], depth_out [T,H,W], normals_out [T,H,W,3] float32 */
+int ug_dc_set_inputs(ug_ctx* ctx, const float* frames_thwc, int T, int H, int W, const float* noise_latents,
+                     const float* noise_aug, const float* intrinsics_t33);
+int ug_dc_run(ug_ctx* ctx, int steps, int decode_chunk, int with_normals);
+int ug_dc_get_outputs(ug_ctx* ctx, float* frames_out, float* depth_out, float* normals_out);
+
+/* Stage-level entry points (host in / host out) - what the parity tests drive.  Each replaces
+ * the corresponding diffusers module call inside the pipeline (un-vendored). */
+int ug_clip_embed(ug_ctx* ctx, const float* frames_thwc, int T, int H, int W, float* emb_out /*[T,proj]*/);
+int ug_vae_encode(ug_ctx* ctx, const float* video_m11_thwc, int T, int H, int W, float* lat_out /*[T,4,H/8,W/8]*/);
+int ug_vae_decode(ug_ctx* ctx, const float* z_tchw, int T, int h, int w, float* frames_out /*[T,8h,8w,3] in [0,1]*/);
+int ug_unet_forward(ug_ctx* ctx, const float* sample_tchw /*[T,Cin,h,w]*/, int T, int h, int w, float timestep,
+                    const float* clip_emb /*[T,cross]*/, float* out_tchw /*[T,Cout,h,w]*/);
+int ug_normals_from_depth(ug_ctx* ctx, const float* depth_thw, const float* intrinsics_t33, int T, int H, int W,
+                          float* normals_out);
+
+/* Op-level entry points for kernel parity tests (row-major host matrices, fp32 in/out, computed in fp16). */
+int ug_op_linear(ug_ctx* ctx, const float* A, int M, int K, const float* W, int N, const float* bias,
+                 const float* R1, float c0, float c1, int act, int geglu, float* out);
+int ug_op_conv(ug_ctx* ctx, const float* x0_thwc, int C0, const float* x1_thwc, int C1, int T, int H, int W,
+               const float* weight /*[O][I][kt][ky][kx]*/, const float* bias, int O, int kt, int k, int stride,
+               int pad_t, int pad_l, int ups, float* out_thwc);
+int ug_op_groupnorm(ug_ctx* ctx, const float* x0, int C0, const float* x1, int C1, int T, int HW, int G, float eps,
+                    int temporal, int silu, const float* gamma, const float* beta, float* out);
+int ug_op_layernorm(ug_ctx* ctx, const float* x, int M, int C, float eps, const float* gamma, const float* beta,
+                    const float* addvec, int rows_per_vec, float* out, float* xout);
+int ug_op_flash_attn(ug_ctx* ctx, const float* qkv /*[B*S,3*H*64]*/, int B, int H, int S, float* out /*[B*S,H*64]*/);
+int ug_op_temporal_attn(ug_ctx* ctx, const float* qkv /*[T*HW,3*H*64]*/, int T, int HW, int H, float* out);
+int ug_op_attention_generic(ug_ctx* ctx, const float* qkv /*[B*S,3*H*d]*/, int B, int S, int H, int d, float* out);
+int ug_op_euler_step(ug_ctx* ctx, const float* v, float* latents_inout, long n, float sigma, float sigma_next);
+
+/* HIP-event profiling of everything launched between begin and end; end returns a JSON
+ * object {kernel_family: {ms, calls, flops, bytes}} valid until the next call on ctx. */
+int ug_profile_begin(ug_ctx* ctx);
+const char* ug_profile_end(ug_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun / the driver's GPU tier)")
+
+
+@pytest.fixture(scope="session")
+def engine():
+    """One HIP context for the whole GPU session.  No fallback: fails loudly without the .so / a GPU."""
+    from unigeo_amd._lib import Engine
+    eng = Engine(0, workspace_bytes=6 << 30, persist_bytes=1 << 30)
+    yield eng
+    eng.close()

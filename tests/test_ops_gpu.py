@@ -1,0 +1,202 @@
+"""Kernel-level parity: every hand-written HIP kernel, driven through the C ABI, against a plain
+torch-CPU fp32 evaluation of the same op on the same (fp16-rounded) inputs.
+
+Tolerance: outputs are stored in fp16 (rel. spacing 2^-11 ~ 4.9e-4) after fp32 accumulation, so the
+bound is a few fp16 ulps of the output scale: max|err| / max|ref| < 2e-3 unless stated."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import assert_close, h16, t
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-3
+
+
+def rnd(rng, *shape, scale=1.0):
+    return h16(rng.standard_normal(shape) * scale)
+
+
+@pytest.mark.parametrize("M,K,N", [(128, 64, 128), (200, 320, 320), (77, 1280, 640), (1200, 2560, 1280),
+                                   (25, 1024, 320), (1, 320, 1280), (300, 72, 8), (513, 136, 200)])
+def test_linear_shapes(engine, M, K, N):
+    rng = np.random.default_rng(M * 7 + K + N)
+    A, W, b = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5), rnd(rng, N)
+    got = engine.op_linear(A, W, b)
+    assert_close(got, A @ W.T + b, TOL, f"linear {M}x{K}x{N}")
+
+
+def test_linear_transpose_detecting(engine):
+    # A = I with an asymmetric W catches any row/col swap in the MFMA output mapping
+    K = 128
+    A = np.eye(K, dtype=np.float32)
+    W = h16(np.arange(K * K).reshape(K, K) % 251 / 251.0)
+    assert_close(engine.op_linear(A, W), W.T, 1e-3, "identity x asymmetric")
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_linear_epilogue(engine, act):
+    rng = np.random.default_rng(act)
+    M, K, N = 260, 192, 320
+    A, W, b, R = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5), rnd(rng, N), rnd(rng, M, N)
+    got = engine.op_linear(A, W, b, R1=R, c0=0.3, c1=0.7, act=act)
+    ref = 0.3 * (A @ W.T + b) + 0.7 * R
+    if act == 1:
+        ref = F.silu(t(ref)).numpy()
+    elif act == 2:
+        ref = F.gelu(t(ref)).numpy()
+    assert_close(got, ref, TOL, f"epilogue act={act}")
+
+
+def test_linear_geglu(engine):
+    rng = np.random.default_rng(5)
+    M, K, inner = 150, 320, 1280
+    A, W, b = rnd(rng, M, K), rnd(rng, 2 * inner, K, scale=K ** -0.5), rnd(rng, 2 * inner)
+    got = engine.op_linear(A, W, b, geglu=True)
+    y = t(A @ W.T + b)
+    h, g = y.chunk(2, dim=-1)
+    assert_close(got, (h * F.gelu(g)).numpy(), TOL, "geglu")
+
+
+def conv_ref(x_thwc, w, b, stride=1, pad=(1, 1, 1, 1), ups=1):
+    x = t(x_thwc).permute(0, 3, 1, 2)
+    if ups == 2:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    x = F.pad(x, pad)
+    y = F.conv2d(x, t(w), None if b is None else t(b), stride=stride)
+    return y.permute(0, 2, 3, 1).numpy()
+
+
+@pytest.mark.parametrize("C,O,H,W", [(64, 64, 8, 8), (320, 320, 12, 16), (128, 64, 6, 10), (8, 320, 8, 8), (320, 4, 8, 8)])
+def test_conv3x3(engine, C, O, H, W):
+    rng = np.random.default_rng(C + O)
+    x, w, b = rnd(rng, 2, H, W, C), rnd(rng, O, C, 3, 3, scale=(9 * C) ** -0.5), rnd(rng, O)
+    got = engine.op_conv(x, w.reshape(O, C, 1, 3, 3), b)
+    assert_close(got, conv_ref(x, w, b), TOL, f"conv3x3 {C}->{O}")
+
+
+def test_conv_stride2_and_vae_asym_pad(engine):
+    rng = np.random.default_rng(11)
+    C, O = 64, 128
+    x, w, b = rnd(rng, 2, 8, 12, C), rnd(rng, O, C, 3, 3, scale=(9 * C) ** -0.5), rnd(rng, O)
+    assert_close(engine.op_conv(x, w.reshape(O, C, 1, 3, 3), b, stride=2), conv_ref(x, w, b, stride=2), TOL, "stride 2 pad 1")
+    got = engine.op_conv(x, w.reshape(O, C, 1, 3, 3), b, stride=2, pad_t=0, pad_l=0)
+    assert_close(got, conv_ref(x, w, b, stride=2, pad=(0, 1, 0, 1)), TOL, "stride 2 pad (0,1,0,1)")
+
+
+def test_conv_upsample_and_concat(engine):
+    rng = np.random.default_rng(12)
+    C0, C1, O = 128, 64, 64
+    x0, x1 = rnd(rng, 2, 6, 8, C0), rnd(rng, 2, 6, 8, C1)
+    w, b = rnd(rng, O, C0 + C1, 3, 3, scale=(9 * (C0 + C1)) ** -0.5), rnd(rng, O)
+    x = np.concatenate([x0, x1], -1)
+    assert_close(engine.op_conv(x0, w.reshape(O, C0 + C1, 1, 3, 3), b, x1=x1), conv_ref(x, w, b), TOL, "concat")
+    w2 = w[:, :C0]
+    assert_close(engine.op_conv(x0, w2.reshape(O, C0, 1, 3, 3), b, ups=2), conv_ref(x0, w2, b, ups=2), TOL, "nearest-2x + conv")
+    w1 = rnd(rng, O, C0 + C1, 1, 1, scale=(C0 + C1) ** -0.5)
+    got = engine.op_conv(x0, w1.reshape(O, C0 + C1, 1, 1, 1), b, x1=x1, k=1, pad_t=0, pad_l=0)
+    assert_close(got, conv_ref(x, w1, b, pad=(0, 0, 0, 0)), TOL, "1x1 shortcut over concat")
+
+
+@pytest.mark.parametrize("T", [1, 3, 8])
+def test_temporal_conv(engine, T):
+    rng = np.random.default_rng(T)
+    C, H, W = 64, 4, 6
+    x, w, b = rnd(rng, T, H, W, C), rnd(rng, C, C, 3, 1, 1, scale=(3 * C) ** -0.5), rnd(rng, C)
+    got = engine.op_conv(x, w, b, kt=3, k=1, pad_t=0, pad_l=0)
+    x5 = t(x).permute(3, 0, 1, 2)[None]
+    ref = F.conv3d(x5, t(w), t(b), padding=(1, 0, 0))[0].permute(1, 2, 3, 0).numpy()
+    assert_close(got, ref, TOL, f"temporal conv T={T}")
+
+
+@pytest.mark.parametrize("C,G,HW,T", [(320, 32, 192, 3), (64, 16, 100, 2), (1280, 32, 48, 2), (32, 8, 4096, 1), (2560, 32, 12, 2)])
+@pytest.mark.parametrize("temporal", [False, True])
+def test_groupnorm(engine, C, G, HW, T, temporal):
+    rng = np.random.default_rng(C + HW)
+    x = rnd(rng, T, HW, C) * 2 + 0.5
+    gm, bt = rnd(rng, C) + 1, rnd(rng, C)
+    got = engine.op_groupnorm(x, G, 1e-6, gm, bt, temporal=temporal, silu=True)
+    xt = t(x)
+    if temporal:
+        y = F.group_norm(xt.permute(2, 0, 1)[None], G, t(gm), t(bt), 1e-6)[0].permute(1, 2, 0)
+    else:
+        y = F.group_norm(xt.permute(0, 2, 1), G, t(gm), t(bt), 1e-6).permute(0, 2, 1)
+    assert_close(got, F.silu(y).numpy(), TOL, f"groupnorm C={C} temporal={temporal}")
+
+
+def test_groupnorm_concat_groups_straddle_sources(engine):
+    rng = np.random.default_rng(3)
+    C0, C1, G, HW, T = 1280, 640, 32, 48, 2        # 60 channels per group: group 21 straddles x0|x1
+    x0, x1 = rnd(rng, T, HW, C0), rnd(rng, T, HW, C1) * 3
+    gm, bt = rnd(rng, C0 + C1) + 1, rnd(rng, C0 + C1)
+    got = engine.op_groupnorm(x0, G, 1e-6, gm, bt, x1=x1)
+    x = t(np.concatenate([x0, x1], -1))
+    ref = F.group_norm(x.permute(0, 2, 1), G, t(gm), t(bt), 1e-6).permute(0, 2, 1).numpy()
+    assert_close(got, ref, TOL, "groupnorm over virtual concat")
+
+
+@pytest.mark.parametrize("C", [64, 320, 640, 1280])
+def test_layernorm(engine, C):
+    rng = np.random.default_rng(C)
+    M = 203
+    x, gm, bt = rnd(rng, M, C) * 2 + 0.3, rnd(rng, C) + 1, rnd(rng, C)
+    got = engine.op_layernorm(x, 1e-5, gm, bt)
+    assert_close(got, F.layer_norm(t(x), (C,), t(gm), t(bt), 1e-5).numpy(), TOL, f"layernorm {C}")
+    av = rnd(rng, 3, C)
+    y, xo = engine.op_layernorm(x, 1e-5, gm, bt, addvec=av, rows_per_vec=70)
+    xs = h16(x + np.repeat(av, 70, 0)[:M])
+    assert_close(xo, xs, 1e-3, "layernorm pre-add write-back")
+    assert_close(y, F.layer_norm(t(xs), (C,), t(gm), t(bt), 1e-5).numpy(), TOL, "layernorm with pre-add")
+
+
+def attn_ref(qkv, B, S, H, d):
+    q, k, v = t(qkv).reshape(B, S, 3, H, d).permute(2, 0, 3, 1, 4)
+    w = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, -1)
+    return (w @ v).permute(0, 2, 1, 3).reshape(B * S, H * d).numpy()
+
+
+@pytest.mark.parametrize("B,H,S", [(1, 1, 64), (2, 2, 48), (2, 1, 192), (1, 2, 200), (1, 1, 1), (2, 5, 768)])
+def test_flash_attention(engine, B, H, S):
+    rng = np.random.default_rng(S + H)
+    qkv = rnd(rng, B * S, 3 * H * 64)
+    assert_close(engine.op_flash_attn(qkv, B, H, S), attn_ref(qkv, B, S, H, 64), TOL, f"flash S={S}")
+
+
+def test_flash_attention_online_softmax_rescale(engine):
+    # a late key with a huge score forces the running-max rescale branch in a later KV tile
+    rng = np.random.default_rng(9)
+    B, H, S = 1, 1, 256
+    qkv = rnd(rng, S, 192)
+    qkv[:, 64:128][200] = h16(qkv[:, 0:64][5] * 6)       # key 200 aligned with query 5
+    assert_close(engine.op_flash_attn(qkv, B, H, S), attn_ref(qkv, B, S, H, 64), TOL, "flash rescale")
+
+
+@pytest.mark.parametrize("T,HW,H", [(25, 12, 2), (5, 7, 1), (1, 4, 1), (32, 3, 2)])
+def test_temporal_attention(engine, T, HW, H):
+    rng = np.random.default_rng(T)
+    qkv = rnd(rng, T * HW, 3 * H * 64)
+    got = engine.op_temporal_attn(qkv, T, HW, H)
+    # sequence over frames for every pixel: [T,HW,...] -> batch = pixel
+    x = qkv.reshape(T, HW, -1).transpose(1, 0, 2).reshape(HW * T, -1)
+    ref = attn_ref(x, HW, T, H, 64).reshape(HW, T, -1).transpose(1, 0, 2).reshape(T * HW, -1)
+    assert_close(got, ref, TOL, f"temporal attention T={T}")
+
+
+@pytest.mark.parametrize("B,S,H,d", [(2, 257, 2, 80), (2, 48, 1, 512), (1, 64, 1, 64)])
+def test_generic_attention(engine, B, S, H, d):
+    rng = np.random.default_rng(S)
+    qkv = rnd(rng, B * S, 3 * H * d)
+    assert_close(engine.op_attention_generic(qkv, B, S, H, d), attn_ref(qkv, B, S, H, d), TOL, f"generic attn d={d}")
+
+
+def test_euler_step(engine):
+    import sys, os
+    from oracle.scheduler import EulerKarrasVPred
+    rng = np.random.default_rng(0)
+    sch = EulerKarrasVPred(); sch.set_timesteps(5)
+    v, x = rnd(rng, 4096), rnd(rng, 4096) * 50
+    for i in range(5):
+        ref = sch.step(torch.from_numpy(v).half(), i, torch.from_numpy(x).half()).float().numpy()
+        got = engine.op_euler_step(v, x, float(sch.sigmas[i]), float(sch.sigmas[i + 1]))
+        assert_close(got, ref, 1e-3, f"euler step {i}")

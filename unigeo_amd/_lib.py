@@ -1,0 +1,302 @@
+"""ctypes binding of libunigeo_hip.so (C ABI: include/unigeo_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or no MI355X is visible
+the import / Engine construction raises.  numpy arrays in, numpy arrays out; torch never
+crosses this boundary.
+"""
+import ctypes as C
+import dataclasses
+import json
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libunigeo_hip.so")
+
+EXPORTS = [
+    "ug_unet_config_default", "ug_vae_config_default", "ug_clip_config_default",
+    "ug_create", "ug_destroy", "ug_last_error", "ug_workspace_peak",
+    "ug_load_tensor", "ug_bind_unet", "ug_bind_vae", "ug_bind_clip",
+    "ug_dc_set_inputs", "ug_dc_run", "ug_dc_get_outputs",
+    "ug_clip_embed", "ug_vae_encode", "ug_vae_decode", "ug_unet_forward", "ug_normals_from_depth",
+    "ug_op_linear", "ug_op_conv", "ug_op_groupnorm", "ug_op_layernorm", "ug_op_flash_attn",
+    "ug_op_temporal_attn", "ug_op_attention_generic", "ug_op_euler_step",
+    "ug_profile_begin", "ug_profile_end",
+]
+
+
+class UNetConfigC(C.Structure):
+    _fields_ = [("in_channels", C.c_int), ("out_channels", C.c_int), ("num_levels", C.c_int),
+                ("block_out_channels", C.c_int * 8), ("num_attention_heads", C.c_int * 8),
+                ("down_has_attn", C.c_int * 8),
+                ("layers_per_block", C.c_int), ("cross_attention_dim", C.c_int),
+                ("addition_time_embed_dim", C.c_int), ("projection_class_embeddings_input_dim", C.c_int),
+                ("norm_groups", C.c_int),
+                ("eps_cross_attn_blocks", C.c_float), ("eps_plain_down_block", C.c_float),
+                ("eps_mid_block", C.c_float), ("eps_up_blocks", C.c_float)]
+
+
+class VAEConfigC(C.Structure):
+    _fields_ = [("in_channels", C.c_int), ("out_channels", C.c_int), ("latent_channels", C.c_int),
+                ("num_levels", C.c_int), ("block_out_channels", C.c_int * 8),
+                ("layers_per_block", C.c_int), ("norm_groups", C.c_int), ("scaling_factor", C.c_float)]
+
+
+class CLIPConfigC(C.Structure):
+    _fields_ = [("hidden_size", C.c_int), ("intermediate_size", C.c_int), ("num_hidden_layers", C.c_int),
+                ("num_attention_heads", C.c_int), ("image_size", C.c_int), ("patch_size", C.c_int),
+                ("projection_dim", C.c_int), ("layer_norm_eps", C.c_float)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C unigeo_amd/csrc`).  The MI355X path has no CPU / PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    fp, ip, vp = C.POINTER(C.c_float), C.c_int, C.c_void_p
+    lib.ug_create.restype = vp
+    lib.ug_create.argtypes = [ip, C.c_size_t, C.c_size_t]
+    lib.ug_destroy.argtypes = [vp]
+    lib.ug_last_error.restype = C.c_char_p
+    lib.ug_last_error.argtypes = [vp]
+    lib.ug_workspace_peak.restype = C.c_size_t
+    lib.ug_workspace_peak.argtypes = [vp]
+    lib.ug_load_tensor.argtypes = [vp, C.c_char_p, ip, ip, C.POINTER(C.c_int64), vp]
+    lib.ug_bind_unet.argtypes = [vp, C.POINTER(UNetConfigC)]
+    lib.ug_bind_vae.argtypes = [vp, C.POINTER(VAEConfigC)]
+    lib.ug_bind_clip.argtypes = [vp, C.POINTER(CLIPConfigC)]
+    lib.ug_dc_set_inputs.argtypes = [vp, vp, ip, ip, ip, vp, vp, vp]
+    lib.ug_dc_run.argtypes = [vp, ip, ip, ip]
+    lib.ug_dc_get_outputs.argtypes = [vp, vp, vp, vp]
+    lib.ug_clip_embed.argtypes = [vp, vp, ip, ip, ip, vp]
+    lib.ug_vae_encode.argtypes = [vp, vp, ip, ip, ip, vp]
+    lib.ug_vae_decode.argtypes = [vp, vp, ip, ip, ip, vp]
+    lib.ug_unet_forward.argtypes = [vp, vp, ip, ip, ip, C.c_float, vp, vp]
+    lib.ug_normals_from_depth.argtypes = [vp, vp, vp, ip, ip, ip, vp]
+    lib.ug_op_linear.argtypes = [vp, vp, ip, ip, vp, ip, vp, vp, C.c_float, C.c_float, ip, ip, vp]
+    lib.ug_op_conv.argtypes = [vp, vp, ip, vp, ip, ip, ip, ip, vp, vp, ip, ip, ip, ip, ip, ip, ip, vp]
+    lib.ug_op_groupnorm.argtypes = [vp, vp, ip, vp, ip, ip, ip, ip, C.c_float, ip, ip, vp, vp, vp]
+    lib.ug_op_layernorm.argtypes = [vp, vp, ip, ip, C.c_float, vp, vp, vp, ip, vp, vp]
+    lib.ug_op_flash_attn.argtypes = [vp, vp, ip, ip, ip, vp]
+    lib.ug_op_temporal_attn.argtypes = [vp, vp, ip, ip, ip, vp]
+    lib.ug_op_attention_generic.argtypes = [vp, vp, ip, ip, ip, ip, vp]
+    lib.ug_op_euler_step.argtypes = [vp, vp, vp, C.c_long, C.c_float, C.c_float]
+    lib.ug_profile_begin.argtypes = [vp]
+    lib.ug_profile_end.restype = C.c_char_p
+    lib.ug_profile_end.argtypes = [vp]
+    _lib = lib
+    return lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _fill8(dst, vals):
+    for i in range(8):
+        dst[i] = int(vals[i]) if i < len(vals) else 0
+
+
+class Engine:
+    """One context = one GPU.  Mirrors, at the C-ABI level, what the reference's pipeline object
+    offers at /root/reference/model/depthcrafter.py:24-34,80-90."""
+
+    def __init__(self, device_id=0, workspace_bytes=2 << 30, persist_bytes=1 << 30):
+        self.lib = load_library()
+        self.ctx = self.lib.ug_create(int(device_id), int(workspace_bytes), int(persist_bytes))
+        if not self.ctx:
+            raise RuntimeError("ug_create failed: " + self.lib.ug_last_error(None).decode())
+        self.device_id = device_id
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.ug_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RuntimeError("libunigeo_hip: " + self.lib.ug_last_error(self.ctx).decode())
+
+    # ---- weights
+    def load_state(self, prefix, state):
+        for name, arr in state.items():
+            a = np.ascontiguousarray(arr)
+            if a.dtype == np.float16:
+                dt = 0
+            elif a.dtype == np.float32:
+                dt = 1
+            else:
+                a = a.astype(np.float32); dt = 1
+            shape = (C.c_int64 * max(a.ndim, 1))(*(a.shape if a.ndim else (1,)))
+            self._ck(self.lib.ug_load_tensor(self.ctx, (prefix + name).encode(), dt, max(a.ndim, 1), shape, _ptr(a)))
+
+    def bind_unet(self, cfg):
+        c = UNetConfigC()
+        c.in_channels, c.out_channels = cfg.in_channels, cfg.out_channels
+        c.num_levels = len(cfg.block_out_channels)
+        _fill8(c.block_out_channels, cfg.block_out_channels)
+        _fill8(c.num_attention_heads, cfg.num_attention_heads)
+        _fill8(c.down_has_attn, [int(b) for b in cfg.down_has_attn])
+        c.layers_per_block, c.cross_attention_dim = cfg.layers_per_block, cfg.cross_attention_dim
+        c.addition_time_embed_dim = cfg.addition_time_embed_dim
+        c.projection_class_embeddings_input_dim = cfg.projection_class_embeddings_input_dim
+        c.norm_groups = cfg.norm_groups
+        c.eps_cross_attn_blocks, c.eps_plain_down_block = cfg.eps_cross_attn_blocks, cfg.eps_plain_down_block
+        c.eps_mid_block, c.eps_up_blocks = cfg.eps_mid_block, cfg.eps_up_blocks
+        self._ck(self.lib.ug_bind_unet(self.ctx, C.byref(c)))
+        self.unet_cfg = cfg
+
+    def bind_vae(self, cfg):
+        c = VAEConfigC()
+        c.in_channels, c.out_channels, c.latent_channels = cfg.in_channels, cfg.out_channels, cfg.latent_channels
+        c.num_levels = len(cfg.block_out_channels)
+        _fill8(c.block_out_channels, cfg.block_out_channels)
+        c.layers_per_block, c.norm_groups, c.scaling_factor = cfg.layers_per_block, cfg.norm_groups, cfg.scaling_factor
+        self._ck(self.lib.ug_bind_vae(self.ctx, C.byref(c)))
+        self.vae_cfg = cfg
+
+    def bind_clip(self, cfg):
+        c = CLIPConfigC()
+        c.hidden_size, c.intermediate_size = cfg.hidden_size, cfg.intermediate_size
+        c.num_hidden_layers, c.num_attention_heads = cfg.num_hidden_layers, cfg.num_attention_heads
+        c.image_size, c.patch_size, c.projection_dim = cfg.image_size, cfg.patch_size, cfg.projection_dim
+        c.layer_norm_eps = cfg.layer_norm_eps
+        self._ck(self.lib.ug_bind_clip(self.ctx, C.byref(c)))
+        self.clip_cfg = cfg
+
+    # ---- pipeline
+    def set_inputs(self, frames, noise_latents, noise_aug, intrinsics=None):
+        f = _f32(frames)
+        T, H, W, _ = f.shape
+        nl, na = _f32(noise_latents).reshape(T, 4, H // 8, W // 8), _f32(noise_aug).reshape(T, 3, H, W)
+        k = None if intrinsics is None else _f32(intrinsics).reshape(T, 3, 3)
+        self._ck(self.lib.ug_dc_set_inputs(self.ctx, _ptr(f), T, H, W, _ptr(nl), _ptr(na), _ptr(k)))
+        self._shape = (T, H, W)
+
+    def run(self, steps, decode_chunk=8, with_normals=False):
+        self._ck(self.lib.ug_dc_run(self.ctx, int(steps), int(decode_chunk), int(bool(with_normals))))
+
+    def get_outputs(self, frames=True, depth=True, normals=False):
+        T, H, W = self._shape
+        fo = np.empty((T, H, W, 3), np.float32) if frames else None
+        do = np.empty((T, H, W), np.float32) if depth else None
+        no = np.empty((T, H, W, 3), np.float32) if normals else None
+        self._ck(self.lib.ug_dc_get_outputs(self.ctx, _ptr(fo), _ptr(do), _ptr(no)))
+        return fo, do, no
+
+    # ---- stages
+    def clip_embed(self, frames):
+        f = _f32(frames); T, H, W, _ = f.shape
+        out = np.empty((T, self.clip_cfg.projection_dim), np.float32)
+        self._ck(self.lib.ug_clip_embed(self.ctx, _ptr(f), T, H, W, _ptr(out)))
+        return out
+
+    def vae_encode(self, video_m11_thwc):
+        f = _f32(video_m11_thwc); T, H, W, _ = f.shape
+        out = np.empty((T, self.vae_cfg.latent_channels, H // 8, W // 8), np.float32)
+        self._ck(self.lib.ug_vae_encode(self.ctx, _ptr(f), T, H, W, _ptr(out)))
+        return out
+
+    def vae_decode(self, z_tchw):
+        z = _f32(z_tchw); T, _, h, w = z.shape
+        out = np.empty((T, h * 8, w * 8, 3), np.float32)
+        self._ck(self.lib.ug_vae_decode(self.ctx, _ptr(z), T, h, w, _ptr(out)))
+        return out
+
+    def unet_forward(self, sample_tchw, timestep, clip_emb):
+        s = _f32(sample_tchw); T, _, h, w = s.shape
+        e = _f32(clip_emb)
+        out = np.empty((T, self.unet_cfg.out_channels, h, w), np.float32)
+        self._ck(self.lib.ug_unet_forward(self.ctx, _ptr(s), T, h, w, float(timestep), _ptr(e), _ptr(out)))
+        return out
+
+    def normals_from_depth(self, depth, intrinsics):
+        d = _f32(depth); T, H, W = d.shape
+        k = _f32(intrinsics).reshape(T, 3, 3)
+        out = np.empty((T, H, W, 3), np.float32)
+        self._ck(self.lib.ug_normals_from_depth(self.ctx, _ptr(d), _ptr(k), T, H, W, _ptr(out)))
+        return out
+
+    # ---- ops (parity tests)
+    def op_linear(self, A, W, bias=None, R1=None, c0=1.0, c1=1.0, act=0, geglu=False):
+        A, W = _f32(A), _f32(W); M, K = A.shape; N = W.shape[0]
+        b = None if bias is None else _f32(bias); r = None if R1 is None else _f32(R1)
+        out = np.empty((M, N // 2 if geglu else N), np.float32)
+        self._ck(self.lib.ug_op_linear(self.ctx, _ptr(A), M, K, _ptr(W), N, _ptr(b), _ptr(r), c0, c1, act, int(geglu), _ptr(out)))
+        return out
+
+    def op_conv(self, x0, weight, bias=None, x1=None, kt=1, k=3, stride=1, pad_t=1, pad_l=1, ups=1):
+        x0 = _f32(x0); T, H, W, C0 = x0.shape
+        x1a = None if x1 is None else _f32(x1); C1 = 0 if x1 is None else x1a.shape[-1]
+        w = _f32(weight); O = w.shape[0]
+        b = None if bias is None else _f32(bias)
+        Ho, Wo = H * ups // stride, W * ups // stride
+        out = np.empty((T, Ho, Wo, O), np.float32)
+        self._ck(self.lib.ug_op_conv(self.ctx, _ptr(x0), C0, _ptr(x1a), C1, T, H, W, _ptr(w), _ptr(b), O, kt, k,
+                                     stride, pad_t, pad_l, ups, _ptr(out)))
+        return out
+
+    def op_groupnorm(self, x0, G, eps, gamma, beta, x1=None, temporal=False, silu=False):
+        x0 = _f32(x0); T, HW, C0 = x0.shape
+        x1a = None if x1 is None else _f32(x1); C1 = 0 if x1 is None else x1a.shape[-1]
+        out = np.empty((T, HW, C0 + C1), np.float32)
+        self._ck(self.lib.ug_op_groupnorm(self.ctx, _ptr(x0), C0, _ptr(x1a), C1, T, HW, G, eps, int(temporal), int(silu),
+                                          _ptr(_f32(gamma)), _ptr(_f32(beta)), _ptr(out)))
+        return out
+
+    def op_layernorm(self, x, eps, gamma, beta, addvec=None, rows_per_vec=1):
+        x = _f32(x); M, Cc = x.shape
+        out = np.empty((M, Cc), np.float32); xout = np.empty((M, Cc), np.float32)
+        av = None if addvec is None else _f32(addvec)
+        self._ck(self.lib.ug_op_layernorm(self.ctx, _ptr(x), M, Cc, eps, _ptr(_f32(gamma)), _ptr(_f32(beta)), _ptr(av),
+                                          rows_per_vec, _ptr(out), _ptr(xout)))
+        return (out, xout) if addvec is not None else out
+
+    def op_flash_attn(self, qkv, B, H, S):
+        q = _f32(qkv); out = np.empty((B * S, H * 64), np.float32)
+        self._ck(self.lib.ug_op_flash_attn(self.ctx, _ptr(q), B, H, S, _ptr(out)))
+        return out
+
+    def op_temporal_attn(self, qkv, T, HW, H):
+        q = _f32(qkv); out = np.empty((T * HW, H * 64), np.float32)
+        self._ck(self.lib.ug_op_temporal_attn(self.ctx, _ptr(q), T, HW, H, _ptr(out)))
+        return out
+
+    def op_attention_generic(self, qkv, B, S, H, d):
+        q = _f32(qkv); out = np.empty((B * S, H * d), np.float32)
+        self._ck(self.lib.ug_op_attention_generic(self.ctx, _ptr(q), B, S, H, d, _ptr(out)))
+        return out
+
+    def op_euler_step(self, v, lat, sigma, sigma_next):
+        v = _f32(v); l = _f32(lat).copy()
+        self._ck(self.lib.ug_op_euler_step(self.ctx, _ptr(v), _ptr(l), l.size, sigma, sigma_next))
+        return l
+
+    # ---- profiling
+    def profile_begin(self):
+        self._ck(self.lib.ug_profile_begin(self.ctx))
+
+    def profile_end(self):
+        return json.loads(self.lib.ug_profile_end(self.ctx).decode())
+
+    def workspace_peak(self):
+        return int(self.lib.ug_workspace_peak(self.ctx))

@@ -1,0 +1,154 @@
+// Shared declarations for the gfx950 (MI355X / CDNA4) DepthCrafter engine.
+// Layout convention everywhere: activations are channels-last fp16, i.e. a [T,H,W,C] video
+// tensor is the row-major matrix [M = T*H*W, C]; weights are [N][K] row-major ("B^T").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdexcept>
+#include <string>
+
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define UG_CHECK(expr)                                                                        \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      throw std::runtime_error(std::string(#expr) + " failed: " + hipGetErrorString(_e) +    \
+                               " at " + __FILE__ + ":" + std::to_string(__LINE__));           \
+  } while (0)
+
+#define UG_REQUIRE(cond, msg)                                                                 \
+  do {                                                                                        \
+    if (!(cond))                                                                              \
+      throw std::runtime_error(std::string("requirement failed: ") + #cond + " : " + (msg) + \
+                               " at " + __FILE__ + ":" + std::to_string(__LINE__));           \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------
+// GEMM / implicit-GEMM convolution  (kernels/gemm.hip)
+//   Out[m,n] = act( c0 * f(acc[m,n] + bias[n] + bias2[n]) + c1*R1[m,n] + c2*R2[m,n] )
+//   acc = sum_k A(m,k) * W[n,k];  A is either a dense row-major matrix or the implicit
+//   im2col view of one/two channels-last tensors (3x3 / 1x1 / (3,1,1) taps, stride 1|2,
+//   optional nearest-2x upsample of the source, optional channel concat of two sources).
+// ---------------------------------------------------------------------------------------
+enum { UG_ACT_NONE = 0, UG_ACT_SILU = 1, UG_ACT_GELU = 2 };
+enum { UG_F_GEGLU = 1, UG_F_OUT_F32 = 2 };
+
+struct GemmP {
+  const f16* A0; const f16* A1;
+  int C0, C1;            // conv: channels of the two sources; dense: C0 = row stride (lda), C1 = 0
+  int M, N, K;
+  int conv;              // 0 dense, 1 implicit conv
+  int T, Hi, Wi, Ho, Wo; // conv: frames, source dims (pre-upsample), output dims
+  int ups, stride, pad_t, pad_l;
+  int kt, ky, kx;        // taps along time / y / x
+  const f16* W; long ldw;
+  const f16* bias; const f16* bias2;
+  const f16* R1; long ldr1; float c1;
+  const f16* R2; long ldr2; float c2;
+  float c0;
+  void* Out; long ldo;
+  int act, flags;
+  const f16* zero;       // >=16 B of zeros in global memory (source for padded / OOB loads)
+  int nb_inner;          // batch = gridDim.z = nb_outer * nb_inner
+  long sA_o, sA_i, sW_o, sW_i, sO_o, sO_i;
+};
+void launch_gemm(const GemmP& p, int batch, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// Normalisation (kernels/norm.hip)
+// ---------------------------------------------------------------------------------------
+// GroupNorm over a (virtual concat of two) channels-last tensor(s); statistics per frame
+// (temporal == 0) or pooled over all T frames (temporal == 1); optional fused SiLU.
+struct GroupNormP {
+  const f16* X0; const f16* X1; int C0, C1;
+  int T, HW, G; float eps; int temporal; int silu;
+  const f16* gamma; const f16* beta;
+  f16* Y;                 // [T*HW, C0+C1]
+  float* ws;              // >= T * G * 2 * nchunk floats (+ T*G*2 for mean/rstd)
+};
+void launch_groupnorm(const GroupNormP& p, hipStream_t s);
+size_t groupnorm_ws_floats(int T, int HW, int C, int G);
+
+// LayerNorm over rows of [M, C]; optional pre-add of a per-frame broadcast vector
+// (x += vec[(m / rows_per_vec) * C + c]) whose sum is also written back to Xout.
+struct LayerNormP {
+  const f16* X; f16* Y; int M, C; float eps;
+  const f16* gamma; const f16* beta;
+  const f16* addvec; int rows_per_vec; f16* Xout;   // optional
+};
+void launch_layernorm(const LayerNormP& p, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// Attention (kernels/attn.hip)
+// ---------------------------------------------------------------------------------------
+// Flash-style self-attention, head_dim 64.  Q/K/V are column slices of row-major matrices
+// (row stride ld*), batch b = frame, rows [b*S, (b+1)*S), head h at columns [h*64, h*64+64).
+struct FlashP {
+  const f16* Q; const f16* K; const f16* V; long ldq, ldk, ldv;
+  f16* O; long ldo;
+  int B, H, S; float scale;
+};
+void launch_flash_attn64(const FlashP& p, hipStream_t s);
+
+// Temporal self-attention: for every pixel p and head h, sequence over the T frames
+// (row of frame t = t*HW + p), head_dim 64, T <= 64.
+struct TemporalAttnP {
+  const f16* Q; const f16* K; const f16* V; long ld;
+  f16* O; long ldo;
+  int T, HW, H; float scale;
+};
+void launch_temporal_attn64(const TemporalAttnP& p, hipStream_t s);
+
+// Row softmax fp32 [rows, ld_in] (first S cols valid) -> fp16 [rows, ld_out], zero tail.
+void launch_softmax_rows(const float* in, long ld_in, f16* out, long ld_out, long rows, int S,
+                         hipStream_t s);
+// Batched transpose: in [B][R][C] (row stride ldi, batch stride sbi) -> out [B][C][Rpad]
+// (row stride ldo >= R, zero tail, batch stride sbo).
+void launch_transpose(const f16* in, long ldi, long sbi, f16* out, long ldo, long sbo, int B, int R,
+                      int C, int nb_inner, long sbi_inner, long sbo_inner, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// Small / memory-bound kernels (kernels/misc.hip)
+// ---------------------------------------------------------------------------------------
+void launch_cast_f32_f16(const float* in, f16* out, long n, hipStream_t s);
+void launch_cast_f16_f32(const f16* in, float* out, long n, hipStream_t s);
+// weight re-layouts (one-off at bind time)
+void launch_permute_conv_w(const f16* in, f16* out, int O, int I, int taps, int Ipad, int Opad,
+                           hipStream_t s);   // [O][I][taps] -> [Opad][taps][Ipad] (zero padded)
+void launch_gather_rows(const f16* in, f16* out, const int* rowmap, int rows, int cols, hipStream_t s);
+void launch_copy2d(const f16* in, long ldi, f16* out, long ldo, long rows, int cols, hipStream_t s);
+void launch_fill_f16(f16* p, float v, long n, hipStream_t s);
+void launch_add_rowvec(const f16* x, const f16* vec, f16* y, long M, int C, int rows_per_vec,
+                       hipStream_t s);      // y[m,c] = x[m,c] + vec[(m/rows_per_vec)*C + c]
+void launch_axpby(const f16* a, const f16* b, f16* y, float ca, float cb, long n, hipStream_t s);
+
+// DepthCrafter pipeline glue
+void launch_prep_video(const float* frames, const float* noise, f16* clip_src, f16* vae_in,
+                       int T, int H, int W, float noise_aug, hipStream_t s);
+void launch_clip_patchify(const f16* video_m11, f16* patches, int T, int H, int W, int S224,
+                          int P, int Kpad, hipStream_t s);
+void launch_init_latents2(const float* noise, f16* lat, float sigma0, int T, long hw, hipStream_t s);
+void launch_silu_f16(const f16* in, f16* out, long n, hipStream_t s);
+void launch_clip_assemble(const f16* patches, const f16* cls, const f16* pos, f16* tok, int T, int np, int d,
+                          hipStream_t s);   // tok[t][0]=cls+pos[0]; tok[t][1+i]=patches[t*np+i]+pos[1+i]
+void launch_make_unet_input(const f16* lat, const f16* cond, f16* x, long pixels, float inv_scale,
+                            hipStream_t s);   // x[p, 0:4] = lat/sqrt(s^2+1), x[p,4:8] = cond
+void launch_euler_step(const f16* v, f16* lat, long n, float sigma, float sigma_next, hipStream_t s);
+void launch_scale_f16(const f16* in, f16* out, float sc, long n, hipStream_t s);
+void launch_pad_channels(const f16* in, int Cin, f16* out, int Cout, long pixels, hipStream_t s);
+void launch_time_conv_out(const f16* x, const f16* w, const f16* b, float* frames_out, int T,
+                          long HW, int Cs, hipStream_t s);  // + (x/2+0.5).clamp(0,1) -> f32 [T,HW,3]
+void launch_depth_post(const float* frames, float* depth, float* minmax_ws, long pixels,
+                       hipStream_t s);        // channel mean, clip-global min-max, 1/(x+0.1)
+void launch_normals(const float* depth, const float* K33, float* normals, int T, int H, int W,
+                    hipStream_t s);

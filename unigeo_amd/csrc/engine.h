@@ -1,0 +1,138 @@
+// MI355X-native DepthCrafter engine: context, device arena, weight registry, model graphs.
+// Host C++ only sequences kernels on one HIP stream; every FLOP of the hot path runs in the
+// hand-written kernels under kernels/.  No PyTorch, no BLAS/MIOpen, no fallback.
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+
+namespace ug {
+
+struct RawTensor { void* dev = nullptr; int dtype = 0; std::vector<long> shape; long numel = 0; bool used = false; };
+
+class Arena {
+ public:
+  void init(size_t bytes);
+  void destroy();
+  void* alloc(size_t bytes);
+  template <class T> T* get(long n) { return (T*)alloc((size_t)n * sizeof(T)); }
+  size_t mark() const { return off_; }
+  void release(size_t m) { off_ = m; }
+  size_t peak() const { return peak_; }
+  size_t capacity() const { return cap_; }
+ private:
+  char* base_ = nullptr; size_t cap_ = 0, off_ = 0, peak_ = 0;
+};
+
+struct Lin { const f16* w = nullptr; const f16* b = nullptr; int in = 0, out = 0; };
+struct Conv { const f16* w = nullptr; const f16* b = nullptr; int cin = 0, cinp = 0, cout = 0, kt = 1, ky = 1, kx = 1; };
+struct Norm { const f16* g = nullptr; const f16* b = nullptr; int c = 0; float eps = 1e-5f; };
+
+struct Res2D { Norm n1, n2; Conv c1, c2, sc; Lin temb; bool has_sc = false, has_temb = false; int tidx = -1; };
+struct ResT { Norm n1, n2; Conv c1, c2; Lin temb; bool has_temb = false; int tidx = -1; };
+struct STRes { Res2D s; ResT t; float alpha = 0.5f; int cin = 0, cout = 0; };
+
+struct Transformer {
+  int C = 0, heads = 0;
+  Norm gn; Lin proj_in, proj_out;
+  Norm ln1, ln3; Lin qkv1, o1, v2, o2, ff1, ff2;
+  Norm ln_in, tln1, tln3; Lin ffin1, ffin2, tqkv, to1, tv2, to2, tff1, tff2;
+  Lin tpe1, tpe2;
+  float alpha = 0.5f;
+  // per-clip caches (device, persistent)
+  f16* frame_emb = nullptr; int frame_emb_T = 0;   // [T][C]
+  f16* cross_sp = nullptr;                          // [T][C]
+  f16* cross_tm = nullptr;                          // [1][C]
+};
+
+struct UNetCfg {
+  int in_ch = 8, out_ch = 4, nlev = 4; int boc[8] = {320, 640, 1280, 1280}; int heads[8] = {5, 10, 20, 20};
+  int has_attn[8] = {1, 1, 1, 0}; int layers = 2, cross_dim = 1024, add_dim = 256, proj_in_dim = 768, groups = 32;
+  float eps_xattn = 1e-6f, eps_down = 1e-5f, eps_mid = 1e-5f, eps_up = 1e-6f;
+};
+struct VAECfg { int in_ch = 3, out_ch = 3, lat = 4, nlev = 4; int boc[8] = {128, 256, 512, 512}; int layers = 2, groups = 32; float scaling = 0.18215f; };
+struct CLIPCfg { int hidden = 1280, inter = 5120, layers = 32, heads = 16, image = 224, patch = 14, proj = 1024; float eps = 1e-5f; };
+
+struct UNet {
+  UNetCfg cfg; bool bound = false;
+  Conv conv_in, conv_out; Norm norm_out;
+  Lin te1, te2, ae1, ae2;
+  struct Down { std::vector<STRes> res; std::vector<Transformer> attn; Conv down; bool has_down = false; };
+  struct Up { std::vector<STRes> res; std::vector<Transformer> attn; Conv up; bool has_up = false; };
+  std::vector<Down> down; std::vector<Up> up;
+  STRes mid0, mid1; Transformer mid_attn;
+  std::vector<Res2D*> temb_s; std::vector<ResT*> temb_t;   // res-blocks with time_emb_proj, in order
+  // per-run caches
+  f16* tproj = nullptr; long tproj_stride = 0; int tproj_steps = 0; std::vector<long> tproj_off_s, tproj_off_t;
+};
+
+struct VAttn { Norm gn; Lin qkv, out; int C = 0; };
+struct VAE {
+  VAECfg cfg; bool bound = false;
+  Conv e_in, e_out, quant; Norm e_norm;
+  struct EDown { std::vector<Res2D> res; Conv down; bool has_down = false; };
+  std::vector<EDown> edown; Res2D emid0, emid1; VAttn eattn;
+  Conv d_in, d_out; Norm d_norm; const f16* tco_w = nullptr; const f16* tco_b = nullptr;
+  std::vector<STRes> dmid; VAttn dattn;
+  struct DUp { std::vector<STRes> res; Conv up; bool has_up = false; };
+  std::vector<DUp> dup;
+};
+
+struct CLIPLayer { Norm ln1, ln2; Lin qkv, out, fc1, fc2; };
+struct CLIP {
+  CLIPCfg cfg; bool bound = false;
+  const f16* patch_w = nullptr; int patch_k = 0;  // [hidden][Kpad]
+  const f16* cls = nullptr; const f16* pos = nullptr;
+  Norm pre, post; std::vector<CLIPLayer> layers; Lin proj;
+};
+
+struct ProfRec { std::string name; double flops, bytes; hipEvent_t e0, e1; };
+
+struct Ctx {
+  int device = 0; hipStream_t stream = nullptr;
+  Arena ws;        // transient activations
+  Arena persist;   // bound weights + per-clip caches
+  f16* zero = nullptr;
+  std::string err;
+  std::unordered_map<std::string, RawTensor> raw;
+  UNet unet; VAE vae; CLIP clip;
+  // profiling
+  bool prof_on = false; std::vector<ProfRec> prof; std::string prof_json;
+  // resident pipeline I/O
+  int T = 0, H = 0, W = 0;
+  float* d_frames = nullptr; float* d_noise_lat = nullptr; float* d_noise_aug = nullptr; float* d_K = nullptr;
+  float* d_out_frames = nullptr; float* d_depth = nullptr; float* d_normals = nullptr; float* d_mm = nullptr;
+  f16* d_clip_emb = nullptr; f16* d_cond = nullptr; f16* d_lat = nullptr;
+  size_t io_mark = 0; bool io_ready = false;
+};
+
+// ---- binding ----
+void upload_raw(Ctx& c, const std::string& name, int dtype, const std::vector<long>& shape, const void* host);
+void bind_unet(Ctx& c, const UNetCfg& cfg, const std::string& prefix);
+void bind_vae(Ctx& c, const VAECfg& cfg, const std::string& prefix);
+void bind_clip(Ctx& c, const CLIPCfg& cfg, const std::string& prefix);
+void finish_binding(Ctx& c, const std::string& prefix);   // fail on unused tensors, free raw
+
+// ---- graphs (device pointers, stream-ordered, transient memory from c.ws) ----
+// x [T,h,w,in_ch] f16; clip_emb [T,cross_dim] f16; tsteps host array of continuous timesteps
+void unet_prepare(Ctx& c, int T, const f16* clip_emb, const float* timesteps, int nsteps);
+f16* unet_forward(Ctx& c, const f16* x, int T, int h, int w, int step);   // -> [T,h,w,out_ch] (ws)
+f16* vae_encode(Ctx& c, const f16* x8, int T, int H, int W);              // x8 [T,H,W,8] -> [T,H/8,W/8,4]
+void vae_decode(Ctx& c, const f16* z, int T, int h, int w, float* frames_out);  // z [T,h,w,4] (already /scaling) -> f32 [T,8h,8w,3]
+f16* clip_embed(Ctx& c, const f16* video_m11, int T, int H, int W);       // [T,H,W,3] -> [T,proj]
+
+// ---- pipeline ----
+void dc_set_inputs(Ctx& c, const float* frames, int T, int H, int W, const float* noise_lat, const float* noise_aug,
+                   const float* K33);
+void dc_run(Ctx& c, int steps, int chunk, int with_normals);
+void dc_get_outputs(Ctx& c, float* frames, float* depth, float* normals);
+
+// profiling helpers
+void prof_begin(Ctx& c);
+std::string prof_end(Ctx& c);
+
+}  // namespace ug

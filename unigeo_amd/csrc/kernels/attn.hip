@@ -1,0 +1,331 @@
+// Attention kernels for gfx950 (head_dim 64, fp16 in, fp32 accumulate / softmax).
+//
+// flash_attn64 (spatial self-attention, S up to thousands):
+//   * workgroup = 4 wave64, 128 query rows of one (frame, head); each wave owns 32 query rows.
+//   * K/V tiles of 64 keys are staged global -> LDS by direct-to-LDS 16-byte loads, double
+//     buffered; the swizzle lives on the source address (LDS image is lane-linear).
+//   * scores are computed TRANSPOSED, S^T = K.Q^T with v_mfma_f32_32x32x16_f16, so every lane
+//     owns one query column: the online-softmax row reductions are in-register plus a single
+//     lane^32 exchange, and the exponentiated P^T registers are already the B operand of the
+//     second MFMA, O^T = V^T.P^T.
+//   * V^T fragments come out of the row-major V tile with the LDS transpose read
+//     ds_read_b64_tr_b16 (no transposed copy of V is ever materialised).
+// temporal_attn64: the same math for the tiny per-pixel sequences over frames (T <= 32); one
+//   wave per (pixel, head), K and Q straight from global into MFMA fragments, V through a
+//   private 4 KiB LDS slab for the transpose read.
+#include "../common.h"
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __fp16 h4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+// K tile swizzle (read with ds_read_b128 by 32 different rows, same logical chunk)
+__device__ __forceinline__ int kswz(int row) { return (row >> 1) & 7; }
+// V tile swizzle (read with the transpose read: 4 rows x 4 chunks per 32 lanes)
+__device__ __forceinline__ int vswz(int row) { return ((row >> 1) & 1) << 2; }
+
+__device__ __forceinline__ f16x4 lds_tr16(const f16* p) {
+  h4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)p);
+  f16x4 o;
+  o[0] = (f16)r[0]; o[1] = (f16)r[1]; o[2] = (f16)r[2]; o[3] = (f16)r[3];
+  return o;
+}
+
+// One 32-key step of O^T += V^T P^T.  vt: LDS V tile [keys][64] (swizzled 16-B chunks), kb = first
+// key row of the 32-key block inside the tile; s[16]: this lane's exponentiated scores.
+__device__ __forceinline__ void pv_block(const f16* vt, int kb, int lane, const float (&pr)[16],
+                                         f32x16 (&o)[2]) {
+  const int L = lane & 15, hh = lane >> 5, db = ((lane >> 4) & 1) * 16;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {      // two K=16 MFMAs cover the 32 keys
+    f16x8 pb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pb[j] = (f16)pr[8 * a + j];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {  // two 32-wide d tiles
+      f16x8 va;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {   // keys (j<4) and +8 (j>=4)
+        const int row = kb + 16 * a + 8 * h + 4 * hh + (L >> 2);
+        const int col = dt * 32 + db + (L & 3) * 4;
+        const int chunk = (col >> 3) ^ vswz(row);
+        const f16x4 t = lds_tr16(vt + row * 64 + chunk * 8 + (col & 7));
+        va[4 * h + 0] = t[0]; va[4 * h + 1] = t[1]; va[4 * h + 2] = t[2]; va[4 * h + 3] = t[3];
+      }
+      o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pb, o[dt], 0, 0, 0);
+    }
+  }
+}
+
+#define FA_KV 64
+
+__global__ __launch_bounds__(256) void flash_attn64_kernel(const FlashP p) {
+  __shared__ __attribute__((aligned(16))) f16 lds[2 * 2 * FA_KV * 64];  // [buf][K|V][64][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const long row0 = (long)b * p.S;
+  const int qi = lane & 31, hh = lane >> 5;
+  const float sc = p.scale * 1.4426950408889634f;
+
+  // Q fragment (B operand of S^T = K Q^T): Q[q = qi][d = c*16 + hh*8 .. +8]
+  f16x8 qf[4];
+  const bool qok = (q0 + qi) < p.S;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (qok) qf[c] = *(const f16x8*)(p.Q + (row0 + q0 + qi) * p.ldq + h * 64 + c * 16 + hh * 8);
+    else qf[c] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  }
+
+  // staging: 64 rows x 128 B per tile = 8 wave-instructions; wave w issues rows [w*16, w*16+16)
+  const int srow0 = wave * 16 + (lane >> 3), pc = lane & 7;
+  auto stage = [&](int kv0, int buf) {
+    f16* kd = lds + buf * (2 * FA_KV * 64);
+    f16* vd = kd + FA_KV * 64;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = srow0 + j * 8;
+      const int key = kv0 + r;
+      const bool ok = key < p.S;
+      const f16* ks = ok ? p.K + (row0 + key) * p.ldk + h * 64 + ((pc ^ kswz(r)) * 8) : (const f16*)nullptr;
+      const f16* vs = ok ? p.V + (row0 + key) * p.ldv + h * 64 + ((pc ^ vswz(r)) * 8) : (const f16*)nullptr;
+      // out-of-range keys: re-read key 0 (always valid); their scores are masked below and
+      // their P is exactly 0, so the (finite) V rows they bring in contribute nothing.
+      if (!ok) { ks = p.K + row0 * p.ldk + h * 64 + pc * 8; vs = p.V + row0 * p.ldv + h * 64 + pc * 8; }
+      __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(kd + (wave * 16 + j * 8) * 64), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)vs, (lptr_t)(vd + (wave * 16 + j * 8) * 64), 16, 0, 0);
+    }
+  };
+
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int ntile = (p.S + FA_KV - 1) / FA_KV;
+  stage(0, 0);
+  int buf = 0;
+  for (int t = 0; t < ntile; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < ntile) stage((t + 1) * FA_KV, buf ^ 1);
+    const f16* kt = lds + buf * (2 * FA_KV * 64);
+    const f16* vt = kt + FA_KV * 64;
+    const int kv0 = t * FA_KV;
+
+    // S^T[key][q] for the two 32-key blocks
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+      const int row = kb * 32 + qi;   // lane's key row inside the tile
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int chunk = (c * 2 + hh) ^ kswz(row);
+        const f16x8 kf = *(const f16x8*)(kt + row * 64 + chunk * 8);
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[c], s[kb], 0, 0, 0);
+      }
+    }
+    // scale (+ mask the key tail in the last tile)
+    float pr[2][16];
+    float mx = -1e30f;
+    const bool tail = (kv0 + FA_KV > p.S);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = s[kb][r] * sc;
+        if (tail) {
+          const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (key >= p.S) v = -1e30f;
+        }
+        pr[kb][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    m_run = m_new;
+    float ps = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = exp2f(pr[kb][r] - m_new);
+        pr[kb][r] = e;
+        ps += e;
+      }
+    l_run = l_run * alpha + ps;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    pv_block(vt, 0, lane, pr[0], o);
+    pv_block(vt, 32, lane, pr[1], o);
+    buf ^= 1;
+  }
+  l_run += __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_run;
+  if (qok) {
+    f16* dst = p.O + (row0 + q0 + qi) * p.ldo + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        f16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (f16)(o[dt][r4 * 4 + e] * inv);
+        *(f16x4*)(dst + dt * 32 + 8 * r4 + 4 * hh) = v;
+      }
+  }
+}
+
+void launch_flash_attn64(const FlashP& p, hipStream_t s) {
+  UG_REQUIRE(p.S >= 1 && p.B >= 1 && p.H >= 1, "flash attention shape");
+  UG_REQUIRE(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0, "flash attention strides");
+  dim3 grid(cdiv(p.S, 128), p.H, p.B);
+  hipLaunchKernelGGL(flash_attn64_kernel, grid, dim3(256), 0, s, p);
+  UG_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------
+// temporal attention: sequence = the T frames of one pixel; one wave per (pixel, head).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void temporal_attn64_kernel(const TemporalAttnP p) {
+  __shared__ __attribute__((aligned(16))) f16 lds[4 * 32 * 64];  // one 32x64 V slab per wave
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long pix = (long)blockIdx.x * 4 + wave;
+  const int h = blockIdx.y;
+  if (pix >= p.HW) return;   // wave-uniform; no block-level barrier is used below
+  const int qi = lane & 31, hh = lane >> 5;
+  const float sc = p.scale * 1.4426950408889634f;
+  f16* vt = lds + wave * (32 * 64);
+  const bool ok = qi < p.T;
+  const long rowq = (long)(ok ? qi : 0) * p.HW + pix;
+
+  // V slab: 32 rows x 128 B = 4 wave-instructions of 8 rows
+  {
+    const int pc = lane & 7;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = j * 8 + (lane >> 3);
+      const int rr = r < p.T ? r : 0;   // padded keys get P == 0
+      const f16* vs = p.V + ((long)rr * p.HW + pix) * p.ld + h * 64 + ((pc ^ vswz(r)) * 8);
+      __builtin_amdgcn_global_load_lds((gptr_t)vs, (lptr_t)(vt + j * 8 * 64), 16, 0, 0);
+    }
+  }
+  f16x8 qf[4], kf[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    qf[c] = *(const f16x8*)(p.Q + rowq * p.ld + h * 64 + c * 16 + hh * 8);
+    kf[c] = *(const f16x8*)(p.K + rowq * p.ld + h * 64 + c * 16 + hh * 8);
+  }
+  f32x16 s;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[c], qf[c], s, 0, 0, 0);
+  float pr[16];
+  float mx = -1e30f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int key = (r & 3) + 8 * (r >> 2) + 4 * hh;
+    float v = s[r] * sc;
+    if (key >= p.T) v = -1e30f;
+    pr[r] = v;
+    mx = fmaxf(mx, v);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float ps = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { pr[r] = exp2f(pr[r] - mx); ps += pr[r]; }
+  ps += __shfl_xor(ps, 32);
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  pv_block(vt, 0, lane, pr, o);
+  if (ok) {
+    const float inv = 1.0f / ps;
+    f16* dst = p.O + rowq * p.ldo + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        f16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (f16)(o[dt][r4 * 4 + e] * inv);
+        *(f16x4*)(dst + dt * 32 + 8 * r4 + 4 * hh) = v;
+      }
+  }
+}
+
+void launch_temporal_attn64(const TemporalAttnP& p, hipStream_t s) {
+  UG_REQUIRE(p.T >= 1 && p.T <= 32, "temporal attention supports up to 32 frames per clip");
+  UG_REQUIRE(p.ld % 8 == 0 && p.ldo % 4 == 0, "temporal attention strides");
+  dim3 grid(cdiv(p.HW, 4), p.H);
+  hipLaunchKernelGGL(temporal_attn64_kernel, grid, dim3(256), 0, s, p);
+  UG_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------
+// Unfused attention helpers (VAE mid-block attention d=512, CLIP d=80): the scores come from
+// the batched GEMM in fp32; these turn them into fp16 probabilities and build V^T.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* in, long ld_in, f16* out, long ld_out,
+                                                           long rows, int S) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* x = in + row * ld_in;
+  float mx = -1e30f;
+  for (int i = lane; i < S; i += 64) mx = fmaxf(mx, x[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float sum = 0.f;
+  for (int i = lane; i < S; i += 64) sum += __expf(x[i] - mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float inv = 1.0f / sum;
+  f16* y = out + row * ld_out;
+  for (int i = lane; i < ld_out; i += 64) y[i] = (i < S) ? (f16)(__expf(x[i] - mx) * inv) : (f16)0.f;
+}
+
+void launch_softmax_rows(const float* in, long ld_in, f16* out, long ld_out, long rows, int S, hipStream_t s) {
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, in, ld_in, out, ld_out, rows, S);
+  UG_CHECK(hipGetLastError());
+}
+
+__global__ void transpose_kernel(const f16* in, long ldi, long sbi, f16* out, long ldo, long sbo, int R, int C,
+                                 int nb_inner, long sbi_i, long sbo_i) {
+  __shared__ f16 tile[32][33];
+  const int bz = blockIdx.z, bo = bz / nb_inner, bi = bz - bo * nb_inner;
+  const f16* src = in + bo * sbi + bi * sbi_i;
+  f16* dst = out + bo * sbo + bi * sbo_i;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    tile[i][threadIdx.x] = (r < R && c < C) ? src[(long)r * ldi + c] : (f16)0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (c < C && r < ldo) dst[(long)c * ldo + r] = tile[threadIdx.x][i];   // r in [R, ldo) gets zeros
+  }
+}
+
+void launch_transpose(const f16* in, long ldi, long sbi, f16* out, long ldo, long sbo, int B, int R, int C,
+                      int nb_inner, long sbi_inner, long sbo_inner, hipStream_t s) {
+  dim3 grid(cdiv(C, 32), cdiv(ldo, 32), B), block(32, 8);
+  hipLaunchKernelGGL(transpose_kernel, grid, block, 0, s, in, ldi, sbi, out, ldo, sbo, R, C, nb_inner, sbi_inner,
+                     sbo_inner);
+  UG_CHECK(hipGetLastError());
+}

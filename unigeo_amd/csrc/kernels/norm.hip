@@ -1,0 +1,262 @@
+// GroupNorm (+SiLU) and LayerNorm for channels-last fp16 activations on gfx950.
+// Both are HBM-bound: 16-byte vector loads/stores, fp32 statistics, wave64 reductions.
+//
+// GroupNorm is three launches:
+//   1. gn_stats    grid (nchunk, T): every thread owns one (or a few) 8-channel vectors and walks
+//                  the rows of its chunk accumulating per-channel sum / sum-of-squares in
+//                  registers; a deterministic LDS tree reduces them to per-group partials.
+//   2. gn_finalize grid (T): fp64 combine of the chunk partials (per frame, or pooled over all
+//                  frames for the temporal res-blocks) -> per-(frame, channel) scale/shift
+//                  a = rstd*gamma, b = beta - mean*rstd*gamma.
+//   3. gn_apply    same decomposition as 1: y = silu(x*a + b), scale/shift held in registers.
+// The input may be the virtual channel-concat of two tensors (UNet up-block skip connections)
+// - group boundaries straddle the two sources there, so the concat cannot be factored out.
+#include "../common.h"
+
+#define GN_THREADS 256
+#define GN_MAXV 3  // vectors per thread => C <= 3*256*8
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+struct GnGeom { int nvec, tpr, rpi, vpt; };
+// nvec 8-channel vectors per row; tpr threads cooperate on a row, rpi rows per iteration,
+// vpt vectors per thread.
+static __host__ __device__ inline GnGeom gn_geom(int C) {
+  GnGeom g;
+  g.nvec = C / 8;
+  if (g.nvec <= GN_THREADS) { g.tpr = g.nvec; g.rpi = GN_THREADS / g.nvec; g.vpt = 1; }
+  else { g.tpr = GN_THREADS; g.rpi = 1; g.vpt = (g.nvec + GN_THREADS - 1) / GN_THREADS; }
+  return g;
+}
+
+__device__ __forceinline__ f16x8 gn_load(const GroupNormP& p, long m, int c) {
+  return (c < p.C0) ? *(const f16x8*)(p.X0 + m * p.C0 + c) : *(const f16x8*)(p.X1 + m * p.C1 + (c - p.C0));
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_stats(const GroupNormP p, int nchunk, int rows_per_chunk) {
+  extern __shared__ float red[];  // [rpi][C][2]
+  const int C = p.C0 + p.C1;
+  const GnGeom gg = gn_geom(C);
+  const int t = blockIdx.y, chunk = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int rsub = tid / gg.tpr, v0 = tid - rsub * gg.tpr;
+  const bool active = rsub < gg.rpi;
+  const int r0 = chunk * rows_per_chunk;
+  const int r1 = min(r0 + rows_per_chunk, p.HW);
+  float s[GN_MAXV][8], q[GN_MAXV][8];
+#pragma unroll
+  for (int k = 0; k < GN_MAXV; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[k][e] = 0.f; q[k][e] = 0.f; }
+  if (active) {
+    for (int r = r0 + rsub; r < r1; r += gg.rpi) {
+      const long m = (long)t * p.HW + r;
+#pragma unroll
+      for (int k = 0; k < GN_MAXV; ++k) {
+        const int v = v0 + k * GN_THREADS;
+        if (k < gg.vpt && v < gg.nvec) {
+          const f16x8 x = gn_load(p, m, v * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float f = (float)x[e]; s[k][e] += f; q[k][e] += f * f; }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < GN_MAXV; ++k) {
+      const int v = v0 + k * GN_THREADS;
+      if (k < gg.vpt && v < gg.nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          red[((long)rsub * C + v * 8 + e) * 2 + 0] = s[k][e];
+          red[((long)rsub * C + v * 8 + e) * 2 + 1] = q[k][e];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int cpg = C / p.G;
+  for (int g = tid; g < p.G; g += GN_THREADS) {
+    float a = 0.f, b = 0.f;
+    for (int rs = 0; rs < gg.rpi; ++rs)
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        a += red[((long)rs * C + c) * 2 + 0];
+        b += red[((long)rs * C + c) * 2 + 1];
+      }
+    float* dst = p.ws + (((long)t * nchunk + chunk) * p.G + g) * 2;
+    dst[0] = a; dst[1] = b;
+  }
+}
+
+__global__ void gn_finalize(const GroupNormP p, int nchunk, float* ab) {
+  // grid (T); shared mean/rstd per group
+  __shared__ float mr[2 * 512];
+  const int C = p.C0 + p.C1, cpg = C / p.G;
+  const int t = blockIdx.x;
+  for (int g = threadIdx.x; g < p.G; g += blockDim.x) {
+    double a = 0.0, b = 0.0;
+    const int tlo = p.temporal ? 0 : t, thi = p.temporal ? p.T : t + 1;
+    for (int tt = tlo; tt < thi; ++tt)
+      for (int ch = 0; ch < nchunk; ++ch) {
+        const float* src = p.ws + (((long)tt * nchunk + ch) * p.G + g) * 2;
+        a += (double)src[0]; b += (double)src[1];
+      }
+    const double n = (double)cpg * p.HW * (p.temporal ? p.T : 1);
+    const double mean = a / n;
+    double var = b / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mr[2 * g] = (float)mean;
+    mr[2 * g + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int g = c / cpg;
+    const float ga = p.gamma ? (float)p.gamma[c] : 1.f, be = p.beta ? (float)p.beta[c] : 0.f;
+    const float a = mr[2 * g + 1] * ga;
+    ab[((long)t * C + c) * 2 + 0] = a;
+    ab[((long)t * C + c) * 2 + 1] = be - mr[2 * g] * a;
+  }
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_apply(const GroupNormP p, int rows_per_chunk, const float* ab) {
+  const int C = p.C0 + p.C1;
+  const GnGeom gg = gn_geom(C);
+  const int t = blockIdx.y, chunk = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int rsub = tid / gg.tpr, v0 = tid - rsub * gg.tpr;
+  if (rsub >= gg.rpi) return;
+  const int r0 = chunk * rows_per_chunk;
+  const int r1 = min(r0 + rows_per_chunk, p.HW);
+  float a[GN_MAXV][8], b[GN_MAXV][8];
+#pragma unroll
+  for (int k = 0; k < GN_MAXV; ++k) {
+    const int v = v0 + k * GN_THREADS;
+    if (k < gg.vpt && v < gg.nvec) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        a[k][e] = ab[((long)t * C + v * 8 + e) * 2 + 0];
+        b[k][e] = ab[((long)t * C + v * 8 + e) * 2 + 1];
+      }
+    }
+  }
+  for (int r = r0 + rsub; r < r1; r += gg.rpi) {
+    const long m = (long)t * p.HW + r;
+#pragma unroll
+    for (int k = 0; k < GN_MAXV; ++k) {
+      const int v = v0 + k * GN_THREADS;
+      if (k < gg.vpt && v < gg.nvec) {
+        const f16x8 x = gn_load(p, m, v * 8);
+        f16x8 y;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float f = (float)x[e] * a[k][e] + b[k][e];
+          if (p.silu) f = silu_f(f);
+          y[e] = (f16)f;
+        }
+        *(f16x8*)(p.Y + m * C + v * 8) = y;
+      }
+    }
+  }
+}
+
+static inline void gn_chunks(int HW, int& nchunk, int& rpc) {
+  rpc = 64;
+  nchunk = cdiv(HW, rpc);
+  if (nchunk > 96) { nchunk = 96; rpc = cdiv(HW, nchunk); nchunk = cdiv(HW, rpc); }
+}
+
+size_t groupnorm_ws_floats(int T, int HW, int C, int G) {
+  int nchunk, rpc;
+  gn_chunks(HW, nchunk, rpc);
+  return (size_t)T * nchunk * G * 2 + (size_t)T * C * 2;
+}
+
+void launch_groupnorm(const GroupNormP& p, hipStream_t s) {
+  const int C = p.C0 + p.C1;
+  UG_REQUIRE(p.C0 % 8 == 0 && p.C1 % 8 == 0, "GroupNorm channels must be multiples of 8");
+  UG_REQUIRE(C % p.G == 0 && p.G <= 512, "GroupNorm group count");
+  UG_REQUIRE(C <= GN_MAXV * GN_THREADS * 8, "GroupNorm too many channels");
+  int nchunk, rpc;
+  gn_chunks(p.HW, nchunk, rpc);
+  const GnGeom gg = gn_geom(C);
+  float* ab = p.ws + (size_t)p.T * nchunk * p.G * 2;
+  const size_t lds = (size_t)gg.rpi * C * 2 * sizeof(float);
+  hipLaunchKernelGGL(gn_stats, dim3(nchunk, p.T), dim3(GN_THREADS), lds, s, p, nchunk, rpc);
+  hipLaunchKernelGGL(gn_finalize, dim3(p.T), dim3(256), 0, s, p, nchunk, ab);
+  hipLaunchKernelGGL(gn_apply, dim3(nchunk, p.T), dim3(GN_THREADS), 0, s, p, rpc, (const float*)ab);
+  UG_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm: one wave64 per row, row held in registers, exact two-pass statistics.
+// ------------------------------------------------------------------------------------------
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_kernel(const LayerNormP p) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.M) return;
+  const int nvec = p.C / 8;
+  float x[VPL][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int v = lane + k * 64;
+    if (v < nvec) {
+      const f16x8 h = *(const f16x8*)(p.X + row * p.C + v * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[k][e] = (float)h[e];
+      if (p.addvec) {
+        const f16x8 a = *(const f16x8*)(p.addvec + (row / p.rows_per_vec) * p.C + v * 8);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { o[e] = (f16)(x[k][e] + (float)a[e]); x[k][e] = (float)o[e]; }
+        if (p.Xout) *(f16x8*)(p.Xout + row * p.C + v * 8) = o;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += x[k][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[k][e] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum / p.C;
+  float var = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int v = lane + k * 64;
+    if (v < nvec) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = x[k][e] - mean; var += d * d; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
+  const float rstd = rsqrtf(var / p.C + p.eps);
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int v = lane + k * 64;
+    if (v < nvec) {
+      const f16x8 g = *(const f16x8*)(p.gamma + v * 8);
+      const f16x8 b = *(const f16x8*)(p.beta + v * 8);
+      f16x8 y;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = (f16)((x[k][e] - mean) * rstd * (float)g[e] + (float)b[e]);
+      *(f16x8*)(p.Y + row * p.C + v * 8) = y;
+    }
+  }
+}
+
+void launch_layernorm(const LayerNormP& p, hipStream_t s) {
+  UG_REQUIRE(p.C % 8 == 0, "LayerNorm C must be a multiple of 8");
+  const int vpl = cdiv(p.C / 8, 64);
+  UG_REQUIRE(vpl <= 4, "LayerNorm C too large");
+  dim3 grid(cdiv(p.M, 4)), block(256);
+  switch (vpl) {
+    case 1: hipLaunchKernelGGL(ln_kernel<1>, grid, block, 0, s, p); break;
+    case 2: hipLaunchKernelGGL(ln_kernel<2>, grid, block, 0, s, p); break;
+    case 3: hipLaunchKernelGGL(ln_kernel<3>, grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL(ln_kernel<4>, grid, block, 0, s, p); break;
+  }
+  UG_CHECK(hipGetLastError());
+}
