@@ -87,6 +87,9 @@ int ug_dc_set_inputs(ug_ctx* ctx, const float* frames_thwc, int T, int H, int W,
                      const float* noise_aug, const float* intrinsics_t33);
 int ug_dc_run(ug_ctx* ctx, int steps, int decode_chunk, int with_normals);
 int ug_dc_get_outputs(ug_ctx* ctx, float* frames_out, float* depth_out, float* normals_out);
+/* Device addresses of the resident outputs (valid until the next ug_dc_set_inputs): lets the caller hand
+ * them to RCCL (torch.distributed) for the cross-GPU gather without a host round trip. */
+int ug_dc_device_ptrs(ug_ctx* ctx, void** frames_dev, void** depth_dev, void** normals_dev);
 
 /* Stage-level entry points (host in / host out) - what the parity tests drive.  Each replaces
  * the corresponding diffusers module call inside the pipeline (un-vendored). */
@@ -116,6 +119,7 @@ int ug_op_euler_step(ug_ctx* ctx, const float* v, float* latents_inout, long n, 
 /* HIP-event profiling of everything launched between begin and end; end returns a JSON
  * object {kernel_family: {ms, calls, flops, bytes}} valid until the next call on ctx. */
 int ug_profile_begin(ug_ctx* ctx);
+int ug_profile_begin_shapes(ug_ctx* ctx);   /* same, keyed by kernel family AND problem shape */
 const char* ug_profile_end(ug_ctx* ctx);
 
 #ifdef __cplusplus

@@ -1,0 +1,27 @@
+"""Build oracle torch modules from a (numpy, fp16) state dict - test helper."""
+import dataclasses
+
+import numpy as np
+import torch
+
+from oracle.clip import CLIPConfig, CLIPVisionWithProjection
+from oracle.svd_unet import UNetConfig, UNetSpatioTemporal
+from oracle.vae import AutoencoderKLTemporalDecoder, VAEConfig
+
+
+def _load(mod, state):
+    sd = {k: torch.from_numpy(np.asarray(v, dtype=np.float32)) for k, v in state.items()}
+    missing, unexpected = mod.load_state_dict(sd, strict=True), None
+    return mod.eval()
+
+
+def oracle_unet(cfg, state):
+    return _load(UNetSpatioTemporal(UNetConfig(**dataclasses.asdict(cfg))), state)
+
+
+def oracle_vae(cfg, state):
+    return _load(AutoencoderKLTemporalDecoder(VAEConfig(**dataclasses.asdict(cfg))), state)
+
+
+def oracle_clip(cfg, state):
+    return _load(CLIPVisionWithProjection(CLIPConfig(**dataclasses.asdict(cfg))), state)

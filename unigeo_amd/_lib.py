@@ -18,11 +18,11 @@ EXPORTS = [
     "ug_unet_config_default", "ug_vae_config_default", "ug_clip_config_default",
     "ug_create", "ug_destroy", "ug_last_error", "ug_workspace_peak",
     "ug_load_tensor", "ug_bind_unet", "ug_bind_vae", "ug_bind_clip",
-    "ug_dc_set_inputs", "ug_dc_run", "ug_dc_get_outputs",
+    "ug_dc_set_inputs", "ug_dc_run", "ug_dc_get_outputs", "ug_dc_device_ptrs",
     "ug_clip_embed", "ug_vae_encode", "ug_vae_decode", "ug_unet_forward", "ug_normals_from_depth",
     "ug_op_linear", "ug_op_conv", "ug_op_groupnorm", "ug_op_layernorm", "ug_op_flash_attn",
     "ug_op_temporal_attn", "ug_op_attention_generic", "ug_op_euler_step",
-    "ug_profile_begin", "ug_profile_end",
+    "ug_profile_begin", "ug_profile_begin_shapes", "ug_profile_end",
 ]
 
 
@@ -77,6 +77,7 @@ def load_library():
     lib.ug_dc_set_inputs.argtypes = [vp, vp, ip, ip, ip, vp, vp, vp]
     lib.ug_dc_run.argtypes = [vp, ip, ip, ip]
     lib.ug_dc_get_outputs.argtypes = [vp, vp, vp, vp]
+    lib.ug_dc_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.ug_clip_embed.argtypes = [vp, vp, ip, ip, ip, vp]
     lib.ug_vae_encode.argtypes = [vp, vp, ip, ip, ip, vp]
     lib.ug_vae_decode.argtypes = [vp, vp, ip, ip, ip, vp]
@@ -91,6 +92,7 @@ def load_library():
     lib.ug_op_attention_generic.argtypes = [vp, vp, ip, ip, ip, ip, vp]
     lib.ug_op_euler_step.argtypes = [vp, vp, vp, C.c_long, C.c_float, C.c_float]
     lib.ug_profile_begin.argtypes = [vp]
+    lib.ug_profile_begin_shapes.argtypes = [vp]
     lib.ug_profile_end.restype = C.c_char_p
     lib.ug_profile_end.argtypes = [vp]
     _lib = lib
@@ -203,6 +205,13 @@ class Engine:
         self._ck(self.lib.ug_dc_get_outputs(self.ctx, _ptr(fo), _ptr(do), _ptr(no)))
         return fo, do, no
 
+    def device_ptrs(self):
+        """(frames, depth, normals) device addresses of the resident outputs + their shapes."""
+        f, d, n = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._ck(self.lib.ug_dc_device_ptrs(self.ctx, C.byref(f), C.byref(d), C.byref(n)))
+        T, H, W = self._shape
+        return {"frames": (f.value, (T, H, W, 3)), "depth": (d.value, (T, H, W)), "normals": (n.value, (T, H, W, 3))}
+
     # ---- stages
     def clip_embed(self, frames):
         f = _f32(frames); T, H, W, _ = f.shape
@@ -292,8 +301,8 @@ class Engine:
         return l
 
     # ---- profiling
-    def profile_begin(self):
-        self._ck(self.lib.ug_profile_begin(self.ctx))
+    def profile_begin(self, shapes=False):
+        self._ck((self.lib.ug_profile_begin_shapes if shapes else self.lib.ug_profile_begin)(self.ctx))
 
     def profile_end(self):
         return json.loads(self.lib.ug_profile_end(self.ctx).decode())

@@ -14,7 +14,7 @@ static std::string g_create_err;
 
 #define UG_TRY(ctx, ...)                                   \
   if (!(ctx)) return -1;                                   \
-  try { __VA_ARGS__; return 0; }                           \
+  try { UG_CHECK(hipSetDevice((ctx)->c.device)); __VA_ARGS__; return 0; } \
   catch (const std::exception& e) { (ctx)->c.err = e.what(); (void)hipGetLastError(); return 1; } \
   catch (...) { (ctx)->c.err = "unknown error"; return 2; }
 
@@ -118,7 +118,17 @@ int ug_dc_set_inputs(ug_ctx* x, const float* frames, int T, int H, int W, const 
 int ug_dc_run(ug_ctx* x, int steps, int chunk, int with_normals) { UG_TRY(x, dc_run(x->c, steps, chunk, with_normals)); }
 int ug_dc_get_outputs(ug_ctx* x, float* f, float* d, float* n) { UG_TRY(x, dc_get_outputs(x->c, f, d, n)); }
 
-int ug_profile_begin(ug_ctx* x) { UG_TRY(x, prof_begin(x->c)); }
+int ug_dc_device_ptrs(ug_ctx* x, void** f, void** d, void** n) {
+  UG_TRY(x, {
+    UG_REQUIRE(x->c.io_ready, "no resident outputs");
+    if (f) *f = x->c.d_out_frames;
+    if (d) *d = x->c.d_depth;
+    if (n) *n = x->c.d_normals;
+  });
+}
+
+int ug_profile_begin(ug_ctx* x) { UG_TRY(x, prof_begin(x->c, false)); }
+int ug_profile_begin_shapes(ug_ctx* x) { UG_TRY(x, prof_begin(x->c, true)); }
 const char* ug_profile_end(ug_ctx* x) {
   if (!x) return "{}";
   try { x->c.prof_json = prof_end(x->c); } catch (const std::exception& e) { x->c.err = e.what(); x->c.prof_json = "{}"; }

@@ -101,7 +101,7 @@ struct Ctx {
   std::unordered_map<std::string, RawTensor> raw;
   UNet unet; VAE vae; CLIP clip;
   // profiling
-  bool prof_on = false; std::vector<ProfRec> prof; std::string prof_json;
+  bool prof_on = false; bool prof_shapes = false; std::vector<ProfRec> prof; std::string prof_json;
   // resident pipeline I/O
   int T = 0, H = 0, W = 0;
   float* d_frames = nullptr; float* d_noise_lat = nullptr; float* d_noise_aug = nullptr; float* d_K = nullptr;
@@ -132,7 +132,7 @@ void dc_run(Ctx& c, int steps, int chunk, int with_normals);
 void dc_get_outputs(Ctx& c, float* frames, float* depth, float* normals);
 
 // profiling helpers
-void prof_begin(Ctx& c);
+void prof_begin(Ctx& c, bool shapes = false);
 std::string prof_end(Ctx& c);
 
 }  // namespace ug

@@ -39,7 +39,7 @@ struct ProfScope {
   }
   ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c.prof[idx].e1, c.stream); }
 };
-void prof_begin(Ctx& c) { c.prof.clear(); c.prof_on = true; }
+void prof_begin(Ctx& c, bool shapes) { c.prof.clear(); c.prof_on = true; c.prof_shapes = shapes; }
 std::string prof_end(Ctx& c) {
   c.prof_on = false;
   UG_CHECK(hipStreamSynchronize(c.stream));
@@ -74,7 +74,10 @@ struct Epi {
 static void run_gemm(Ctx& c, GemmP p, int batch, const char* tag) {
   p.zero = c.zero;
   if (p.nb_inner < 1) p.nb_inner = 1;
-  ProfScope ps(c, tag, 2.0 * p.M * p.N * (double)p.K * batch, 0);
+  char nm[128];
+  if (c.prof_on && c.prof_shapes) snprintf(nm, sizeof(nm), "%s:%dx%dx%d%s", tag, p.M, p.N, p.K, batch > 1 ? "b" : "");
+  else snprintf(nm, sizeof(nm), "%s", tag);
+  ProfScope ps(c, nm, 2.0 * p.M * p.N * (double)p.K * batch, 0);
   launch_gemm(p, batch, c.stream);
 }
 
@@ -119,7 +122,10 @@ static void groupnorm(Ctx& c, const f16* x0, int C0, const f16* x1, int C1, int 
   const size_t mk = c.ws.mark();
   p.ws = c.ws.get<float>((long)groupnorm_ws_floats(T, HW, n.c, G));
   {
-    ProfScope ps(c, "groupnorm", 0, (double)T * HW * n.c * 2.0 * 3.0);
+    char nm[96];
+    if (c.prof_on && c.prof_shapes) snprintf(nm, sizeof(nm), "groupnorm:T%dxHW%dxC%d%s", T, HW, n.c, temporal ? "t" : "");
+    else snprintf(nm, sizeof(nm), "groupnorm");
+    ProfScope ps(c, nm, 0, (double)T * HW * n.c * 2.0 * 3.0);
     launch_groupnorm(p, c.stream);
   }
   c.ws.release(mk);   // stream-ordered: later kernels that reuse this memory run after the GN kernels
@@ -592,7 +598,10 @@ static f16* transformer_forward(Ctx& c, const Transformer& tr, const f16* x, int
   {
     FlashP p; p.Q = qkv; p.K = qkv + C; p.V = qkv + 2 * C; p.ldq = p.ldk = p.ldv = 3 * C; p.O = ao; p.ldo = C;
     p.B = T; p.H = tr.heads; p.S = HW; p.scale = 0.125f;
-    ProfScope ps(c, "flash_attn", 4.0 * T * tr.heads * (double)HW * HW * 64, 0);
+    char nm[96];
+    if (c.prof_on && c.prof_shapes) snprintf(nm, sizeof(nm), "flash_attn:B%dxH%dxS%d", T, tr.heads, HW);
+    else snprintf(nm, sizeof(nm), "flash_attn");
+    ProfScope ps(c, nm, 4.0 * T * tr.heads * (double)HW * HW * 64, 0);
     launch_flash_attn64(p, c.stream);
   }
   f16* h1 = c.ws.get<f16>(M * C);

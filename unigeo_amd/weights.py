@@ -255,7 +255,12 @@ def random_state(manifest, seed: int, dtype=np.float16) -> Dict[str, np.ndarray]
             a = 0.1 * rng.standard_normal(shape)
         else:
             fan_in = int(np.prod(shape[1:]))
-            a = rng.standard_normal(shape, dtype=np.float32) * (1.0 / np.sqrt(fan_in))
+            n = int(np.prod(shape))
+            if n > (1 << 22):   # big tensors: tile a 4M-sample block (keeps full-size weight synthesis to seconds)
+                a = np.resize(rng.standard_normal(1 << 22, dtype=np.float32), n).reshape(shape)
+            else:
+                a = rng.standard_normal(shape, dtype=np.float32)
+            a = a * np.float32(1.0 / np.sqrt(fan_in))
         out[name] = np.ascontiguousarray(a.astype(dtype))
     return out
 
