@@ -116,6 +116,12 @@ int ug_op_temporal_attn(ug_ctx* ctx, const float* qkv /*[T*HW,3*H*64]*/, int T, 
 int ug_op_attention_generic(ug_ctx* ctx, const float* qkv /*[B*S,3*H*d]*/, int B, int S, int H, int d, float* out);
 int ug_op_euler_step(ug_ctx* ctx, const float* v, float* latents_inout, long n, float sigma, float sigma_next);
 
+/* Tuning aids (not on the product path): GEMM / implicit-conv microbenchmark on device-resident random data,
+ * and an override of the tile/split-K heuristic (-1 = heuristic). ms_out: [ms per launch, cfg, split, M, K]. */
+int ug_bench_gemm(ug_ctx* ctx, int M, int N, int K, int conv, int T, int Hi, int Wi, int C0, int C1, int kt, int k,
+                  int stride, int ups, int cfg, int split, int iters, float* ms_out);
+int ug_tune_force(int cfg, int split);
+
 /* HIP-event profiling of everything launched between begin and end; end returns a JSON
  * object {kernel_family: {ms, calls, flops, bytes}} valid until the next call on ctx. */
 int ug_profile_begin(ug_ctx* ctx);

@@ -22,7 +22,7 @@ EXPORTS = [
     "ug_clip_embed", "ug_vae_encode", "ug_vae_decode", "ug_unet_forward", "ug_normals_from_depth",
     "ug_op_linear", "ug_op_conv", "ug_op_groupnorm", "ug_op_layernorm", "ug_op_flash_attn",
     "ug_op_temporal_attn", "ug_op_attention_generic", "ug_op_euler_step",
-    "ug_profile_begin", "ug_profile_begin_shapes", "ug_profile_end",
+    "ug_profile_begin", "ug_profile_begin_shapes", "ug_profile_end", "ug_bench_gemm", "ug_tune_force",
 ]
 
 
@@ -92,6 +92,8 @@ def load_library():
     lib.ug_op_attention_generic.argtypes = [vp, vp, ip, ip, ip, ip, vp]
     lib.ug_op_euler_step.argtypes = [vp, vp, vp, C.c_long, C.c_float, C.c_float]
     lib.ug_profile_begin.argtypes = [vp]
+    lib.ug_bench_gemm.argtypes = [vp] + [ip] * 16 + [vp]
+    lib.ug_tune_force.argtypes = [ip, ip]
     lib.ug_profile_begin_shapes.argtypes = [vp]
     lib.ug_profile_end.restype = C.c_char_p
     lib.ug_profile_end.argtypes = [vp]
@@ -299,6 +301,16 @@ class Engine:
         v = _f32(v); l = _f32(lat).copy()
         self._ck(self.lib.ug_op_euler_step(self.ctx, _ptr(v), _ptr(l), l.size, sigma, sigma_next))
         return l
+
+    def bench_gemm(self, M=0, N=0, K=0, conv=None, cfg=-1, split=0, iters=20):
+        """conv = dict(T,H,W,C0,C1,kt,k,stride,ups) or None (dense).  Returns (ms, TFLOP/s, cfg, split)."""
+        out = np.zeros(8, np.float32)
+        cv = conv or {}
+        self._ck(self.lib.ug_bench_gemm(self.ctx, M, N, K, int(conv is not None), cv.get("T", 0), cv.get("H", 0), cv.get("W", 0),
+                                        cv.get("C0", 0), cv.get("C1", 0), cv.get("kt", 1), cv.get("k", 1), cv.get("stride", 1),
+                                        cv.get("ups", 1), cfg, split, iters, _ptr(out)))
+        Mr, Kr = float(out[3]), float(out[4])
+        return float(out[0]), 2.0 * Mr * N * Kr / (out[0] * 1e-3) / 1e12, int(out[1]), int(out[2])
 
     # ---- profiling
     def profile_begin(self, shapes=False):

@@ -273,6 +273,7 @@ int ug_op_linear(ug_ctx* x, const float* A, int M, int K, const float* W, int N,
     GemmP p; memset(&p, 0, sizeof(p));
     p.A0 = dA; p.C0 = K; p.M = M; p.N = N; p.K = K; p.W = dW; p.ldw = K; p.bias = db; p.R1 = dR; p.ldr1 = Nout;
     p.c0 = c0; p.c1 = c1; p.act = act; p.flags = geglu ? UG_F_GEGLU : 0; p.Out = dO; p.ldo = Nout; p.zero = c.zero; p.nb_inner = 1;
+    { int cf, sp; gemm_plan(p, 1, &cf, &sp); p.cfg_p1 = cf + 1; p.splitk = sp; if (sp > 1) p.partial = c.ws.get<float>((long)sp * M * N); }
     launch_gemm(p, 1, c.stream);
     down16(c, dO, out, (long)M * Nout);
   });
@@ -296,6 +297,7 @@ int ug_op_conv(ug_ctx* x, const float* x0, int C0, const float* x1, int C1, int 
     p.ups = ups; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l; p.kt = kt; p.ky = k; p.kx = k;
     p.M = T * Ho * Wo; p.N = O; p.K = I * taps; p.W = dW; p.ldw = p.K; p.bias = db; p.c0 = 1.f;
     p.Out = dO; p.ldo = O; p.zero = c.zero; p.nb_inner = 1;
+    { int cf, sp; gemm_plan(p, 1, &cf, &sp); p.cfg_p1 = cf + 1; p.splitk = sp; if (sp > 1) p.partial = c.ws.get<float>((long)sp * p.M * p.N); }
     launch_gemm(p, 1, c.stream);
     down16(c, dO, out, (long)T * Ho * Wo * O);
   });
@@ -367,6 +369,42 @@ int ug_op_attention_generic(ug_ctx* x, const float* qkv, int B, int S, int H, in
     f16* dq = up16(c, qkv, M * 3 * C); f16* o = c.ws.get<f16>(M * C);
     test_unfused_attention(c, dq, 3 * C, B, S, H, d, o, C);
     down16(c, o, out, M * C);
+  });
+}
+
+int ug_tune_force(int cfg, int split) { gemm_force(cfg, split); return 0; }
+
+// GEMM / conv microbenchmark on device-resident pseudo-random data: average ms per launch over `iters`.
+int ug_bench_gemm(ug_ctx* x, int M, int N, int K, int conv, int T, int Hi, int Wi, int C0, int C1, int kt, int k,
+                  int stride, int ups, int cfg, int split, int iters, float* ms_out) {
+  UG_TRY(x, {
+    Ctx& c = x->c; Scope sc(c);
+    GemmP p; memset(&p, 0, sizeof(p));
+    long asz;
+    if (conv) {
+      p.conv = 1; p.T = T; p.Hi = Hi; p.Wi = Wi; p.ups = ups; p.stride = stride; p.kt = kt; p.ky = k; p.kx = k;
+      p.pad_t = k / 2; p.pad_l = k / 2; p.Ho = Hi * ups / stride; p.Wo = Wi * ups / stride;
+      p.C0 = C0; p.C1 = C1; M = T * p.Ho * p.Wo; K = (C0 + C1) * kt * k * k;
+      asz = (long)T * Hi * Wi * C0;
+    } else { p.C0 = K; asz = (long)M * K; }
+    f16* A = c.ws.get<f16>(asz); f16* A1 = C1 ? c.ws.get<f16>((long)T * Hi * Wi * C1) : nullptr;
+    f16* Wt = c.ws.get<f16>((long)N * K); f16* O = c.ws.get<f16>((long)M * N); f16* b = c.ws.get<f16>(N);
+    launch_fill_random(A, asz, 1, c.stream); if (A1) launch_fill_random(A1, (long)T * Hi * Wi * C1, 2, c.stream);
+    launch_fill_random(Wt, (long)N * K, 3, c.stream); launch_fill_random(b, N, 4, c.stream);
+    p.A0 = A; p.A1 = A1; p.M = M; p.N = N; p.K = K; p.W = Wt; p.ldw = K; p.bias = b; p.c0 = 1.f; p.Out = O; p.ldo = N;
+    p.zero = c.zero; p.nb_inner = 1;
+    int cf = cfg, sp = split;
+    if (cf < 0 || sp < 1) { int c2, s2; gemm_plan(p, 1, &c2, &s2); if (cf < 0) cf = c2; if (sp < 1) sp = s2; }
+    p.cfg_p1 = cf + 1; p.splitk = sp;
+    if (sp > 1) p.partial = c.ws.get<float>((long)sp * M * N);
+    for (int i = 0; i < 2; ++i) launch_gemm(p, 1, c.stream);
+    hipEvent_t e0, e1; UG_CHECK(hipEventCreate(&e0)); UG_CHECK(hipEventCreate(&e1));
+    UG_CHECK(hipEventRecord(e0, c.stream));
+    for (int i = 0; i < iters; ++i) launch_gemm(p, 1, c.stream);
+    UG_CHECK(hipEventRecord(e1, c.stream)); UG_CHECK(hipEventSynchronize(e1));
+    float ms; UG_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    ms_out[0] = ms / iters; ms_out[1] = (float)cf; ms_out[2] = (float)sp; ms_out[3] = (float)M; ms_out[4] = (float)K;
   });
 }
 

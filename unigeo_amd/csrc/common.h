@@ -41,7 +41,7 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //   optional nearest-2x upsample of the source, optional channel concat of two sources).
 // ---------------------------------------------------------------------------------------
 enum { UG_ACT_NONE = 0, UG_ACT_SILU = 1, UG_ACT_GELU = 2 };
-enum { UG_F_GEGLU = 1, UG_F_OUT_F32 = 2 };
+enum { UG_F_GEGLU = 1, UG_F_OUT_F32 = 2, UG_F_NOXCD = 4 };
 
 struct GemmP {
   const f16* A0; const f16* A1;
@@ -61,8 +61,13 @@ struct GemmP {
   const f16* zero;       // >=16 B of zeros in global memory (source for padded / OOB loads)
   int nb_inner;          // batch = gridDim.z = nb_outer * nb_inner
   long sA_o, sA_i, sW_o, sW_i, sO_o, sO_i;
+  int cfg_p1;            // 0 = pick the tile config automatically, else tile config id + 1
+  int splitk;            // 0 = automatic, 1 = off, >1 = K slices (needs `partial`)
+  float* partial;        // split-K scratch: splitk * M * N floats
 };
 void launch_gemm(const GemmP& p, int batch, hipStream_t s);
+void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out);   // heuristic used when cfg/splitk are 0
+void gemm_force(int cfg, int split);                                       // tuning aid: override the heuristic (-1 = off)
 
 // ---------------------------------------------------------------------------------------
 // Normalisation (kernels/norm.hip)
@@ -128,6 +133,7 @@ void launch_permute_conv_w(const f16* in, f16* out, int O, int I, int taps, int 
 void launch_gather_rows(const f16* in, f16* out, const int* rowmap, int rows, int cols, hipStream_t s);
 void launch_copy2d(const f16* in, long ldi, f16* out, long ldo, long rows, int cols, hipStream_t s);
 void launch_fill_f16(f16* p, float v, long n, hipStream_t s);
+void launch_fill_random(f16* p, long n, unsigned seed, hipStream_t s);   // uniform [-1,1) hash noise
 void launch_add_rowvec(const f16* x, const f16* vec, f16* y, long M, int C, int rows_per_vec,
                        hipStream_t s);      // y[m,c] = x[m,c] + vec[(m/rows_per_vec)*C + c]
 void launch_axpby(const f16* a, const f16* b, f16* y, float ca, float cb, long n, hipStream_t s);

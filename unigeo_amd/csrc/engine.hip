@@ -77,8 +77,16 @@ static void run_gemm(Ctx& c, GemmP p, int batch, const char* tag) {
   char nm[128];
   if (c.prof_on && c.prof_shapes) snprintf(nm, sizeof(nm), "%s:%dx%dx%d%s", tag, p.M, p.N, p.K, batch > 1 ? "b" : "");
   else snprintf(nm, sizeof(nm), "%s", tag);
-  ProfScope ps(c, nm, 2.0 * p.M * p.N * (double)p.K * batch, 0);
-  launch_gemm(p, batch, c.stream);
+  int cfg, split;
+  gemm_plan(p, batch, &cfg, &split);
+  p.cfg_p1 = cfg + 1; p.splitk = split;
+  const size_t mk = c.ws.mark();
+  if (split > 1) p.partial = c.ws.get<float>((long)split * p.M * p.N);
+  {
+    ProfScope ps(c, nm, 2.0 * p.M * p.N * (double)p.K * batch, 0);
+    launch_gemm(p, batch, c.stream);
+  }
+  c.ws.release(mk);
 }
 
 // Out[M, lin.out] = A[M, lin.in] W^T (+bias) ...

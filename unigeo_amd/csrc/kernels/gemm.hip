@@ -2,46 +2,76 @@
 //
 //   Out[M,N] = epilogue( A[M,K] . W[N,K]^T )
 //
-// * 128 x BN x 64 block tile (BN = 128 or 64), 256 threads = 4 wave64 in a 2x2 grid, each wave
-//   owning a 64 x (BN/2) accumulator made of 16x16x32 f16 MFMA tiles (fp32 accumulate).
-// * Operand tiles are staged global -> LDS with the direct-to-LDS 16-byte loads
-//   (global_load_lds_dwordx4): no VGPR round trip.  The LDS image is lane-linear, so the
-//   XOR swizzle that makes the ds_read_b128 fragment reads bank-conflict free is applied on
-//   the per-lane *source* address (chunk ^= (row>>1)&7) and mirrored on the read side.
-// * Double-buffered LDS, one barrier per K-tile: the prefetch of tile t+1 is issued right
-//   after the barrier and lands while tile t is multiplied.
-// * The A operand is either a dense row-major matrix or the im2col view of channels-last
-//   tensors generated on the fly by the address computation (taps over t/y/x, stride,
-//   nearest-2x upsample, concat of two sources).  Padding / out-of-range rows read a zero page.
-// * MFMA operands are swapped (W fragment as "A", activation fragment as "B") and the W rows of
-//   a tile are permuted when they are staged, so every lane ends up with 16 (BN=128) or 8
-//   (BN=64) *contiguous* output columns of one output row: bias / residual / GEGLU / store are
-//   all 16-byte vector operations.
+// * BM x BN x BK block tile, WMW x WNW wave64 grid, every wave owns a (BM/WMW) x (BN/WNW) accumulator made of
+//   16x16x32 f16 MFMA tiles (fp32 accumulate).  Tile shapes are picked per problem (launch_gemm).
+// * Operand tiles are staged global -> LDS with the direct-to-LDS 16-byte loads (global_load_lds_dwordx4): no
+//   VGPR round trip.  The LDS image is lane-linear, so the XOR swizzle that makes the ds_read_b128 fragment
+//   reads bank-conflict free is applied on the per-lane *source* address and mirrored on the read side.
+// * Double-buffered LDS, one barrier per K-tile: the prefetch of tile t+1 is issued right after the barrier
+//   and lands while tile t is multiplied.
+// * The A operand is either a dense row-major matrix or the im2col view of channels-last tensors generated on
+//   the fly by the address computation (taps over t/y/x, stride, nearest-2x upsample, concat of two sources).
+//   Padding / out-of-range rows read a zero page.
+// * MFMA operands are swapped (W fragment as "A", activation fragment as "B") and the W rows of a tile are
+//   permuted when they are staged, so every lane ends up with 4*NT *contiguous* output columns of one output
+//   row: bias / residual / GEGLU / store are all 16-byte vector operations.
+// * split-K (long-K, few-tile problems: the low-resolution UNet levels): gridDim.y slices of K write fp32
+//   partial tiles; splitk_epilogue sums them in a fixed order (deterministic) and applies the epilogue.
 #include "../common.h"
-
-#define BM 128
-#define BK 64
+#include <algorithm>
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7, far below the fp16 output spacing): ~12 VALU ops + one
+// exp instead of libm's erff - the GEGLU epilogue evaluates it 8x per output row per lane.
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float y = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+  const float r = 1.0f - y * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
-template <int BN, bool CONV, bool UNI>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
-  constexpr int NT = BN / 32;   // 16-wide MFMA column tiles per wave
-  constexpr int WID = 4 * NT;   // contiguous output columns per lane
-  extern __shared__ __attribute__((aligned(16))) f16 smem[];
-  f16* As = smem;                    // [2][BM*BK]
-  f16* Bs = smem + 2 * BM * BK;      // [2][BN*BK]
+// 16-byte-chunk swizzle of a [rows][BK] fp16 LDS tile: makes 16 consecutive rows reading the same logical
+// chunk land on 16 distinct 16-byte slots of the 256-byte bank row.
+template <int BK> __device__ __forceinline__ int swz(int row) {
+  if (BK == 64) return (row >> 1) & 7;   // 128-B rows, 2 rows per bank row
+  else return (row >> 2) & 3;            // 64-B rows, 4 rows per bank row
+}
+
+// waves per SIMD the LDS footprint allows (workgroups per CU x waves per workgroup / 4 SIMDs): handed to
+// __launch_bounds__ so the register allocator does not trade that occupancy away.
+template <int BM, int BN, int BK, int NST, int WMW, int WNW> struct GemmOcc {
+  static constexpr int lds = NST * (BM + BN) * BK * 2;
+  static constexpr int wg_lds = (160 * 1024) / lds;
+  static constexpr int wg = wg_lds < 1 ? 1 : (wg_lds > 4 ? 4 : wg_lds);
+  static constexpr int wps_raw = wg * WMW * WNW / 4;
+  static constexpr int wps = wps_raw < 1 ? 1 : (wps_raw > 4 ? 4 : wps_raw);
+};
+
+template <int BM, int BN, int BK, int NST, int WMW, int WNW, bool CONV, bool UNI>
+__global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>::wps)) void gemm_kernel(const GemmP p) {
+  constexpr int NWAVE = WMW * WNW;
+  constexpr int WTM = BM / WMW, WTN = BN / WNW;     // wave tile
+  constexpr int MT = WTM / 16, NT = WTN / 16;       // MFMA tiles per wave
+  constexpr int WID = 4 * NT;                       // contiguous output columns per lane
+  constexpr int CPR = BK / 8;                       // 16-byte chunks per LDS row
+  constexpr int RPI = 64 / CPR;                     // rows covered by one wave-wide 1 KiB load
+  constexpr int AI = BM / RPI / NWAVE;              // A load instructions per wave per K-tile
+  constexpr int BI = BN / RPI / NWAVE;              // W load instructions per wave per K-tile
+  constexpr int STAGE = (BM + BN) * BK;             // halves per pipeline stage
+  static_assert(AI >= 1 && BI >= 1 && (BM / RPI) % NWAVE == 0 && (BN / RPI) % NWAVE == 0, "tile/wave mismatch");
+  static_assert(NST >= 2 && NST <= 4, "pipeline depth");
+  extern __shared__ __attribute__((aligned(16))) f16 smem[];   // [NST][A tile | W tile]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int ntn = (p.N + BN - 1) / BN;
-  const int tn = blockIdx.x % ntn, tm = blockIdx.x / ntn;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int wm = wave / WNW, wn = wave % WNW;
+  const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+  const int ntiles = ntm * ntn;
 
   const int bz = blockIdx.z;
   const int bo = bz / p.nb_inner, bi = bz - bo * p.nb_inner;
@@ -49,59 +79,113 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   const f16* Wb = p.W + bo * p.sW_o + bi * p.sW_i;
   const long out_off = bo * p.sO_o + bi * p.sO_i;
 
-  const int pc = lane & 7;   // physical 16-byte chunk inside the 128-byte LDS row
+  const int pc = lane % CPR;         // physical 16-byte chunk inside the LDS row
+  const int lrow = lane / CPR;       // row inside one 1 KiB load
   const int Cin = p.C0 + p.C1;
 
-  // ---- per-thread A rows ----
-  int a_lc[4];               // logical chunk (after un-swizzling)
-  bool a_ok[4];
-  const f16* a_ptr[4];       // dense: row base pointer
-  int a_t[4], a_y[4], a_x[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int r = (wave * 4 + j) * 8 + (lane >> 3);
-    a_lc[j] = pc ^ ((r >> 1) & 7);
-    const int m = m0 + r;
-    a_ok[j] = m < p.M;
-    if (CONV) {
-      const int hw = p.Ho * p.Wo;
-      const int t = m / hw, rem = m - t * hw;
-      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      a_t[j] = t; a_y[j] = oy * p.stride - p.pad_t; a_x[j] = ox * p.stride - p.pad_l;
-      a_ptr[j] = nullptr;
-    } else {
-      a_ptr[j] = A0 + (long)m * p.C0;
-      a_t[j] = a_y[j] = a_x[j] = 0;
-    }
+  // K range of this split
+  const int nk_all = (p.K + BK - 1) / BK;
+  int kt_lo = 0, kt_hi = nk_all;
+  if (p.splitk > 1) {
+    const int per = (nk_all + p.splitk - 1) / p.splitk;
+    kt_lo = min(nk_all, (int)blockIdx.y * per);
+    kt_hi = min(nk_all, kt_lo + per);
   }
-  // ---- per-thread W rows (permuted: LDS row lr holds W row n0 + perm(lr)) ----
-  int b_lc[NT];
-  const f16* b_ptr[NT];
-  bool b_ok[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int lr = (wave * NT + j) * 8 + (lane >> 3);
-    b_lc[j] = pc ^ ((lr >> 1) & 7);
-    const int half = lr / (BN / 2), rem = lr % (BN / 2);
-    const int jj = rem >> 4, i = rem & 15;
-    const int nloc = half * (BN / 2) + (i >> 2) * WID + jj * 4 + (i & 3);
-    const int n = n0 + nloc;
-    b_ok[j] = n < p.N;
-    b_ptr[j] = Wb + (long)n * p.ldw;
-  }
+  const int nk = max(kt_hi - kt_lo, 1);   // an empty split still walks one (all-zero-source) step
 
-  auto stage = [&](int kt0, int buf) {
-    // A tile
-    int it = 0, iy = 0, ix = 0, cb = 0;
-    if (CONV && UNI) {  // whole 64-wide K tile sits inside one tap
-      const int tap = kt0 / Cin;
-      cb = kt0 - tap * Cin;
-      it = tap / (p.ky * p.kx);
-      const int r2 = tap - it * (p.ky * p.kx);
-      iy = r2 / p.kx; ix = r2 - iy * p.kx;
+  // Persistent tile walk.  Workgroup w (observed to run on XCD w % 8) takes, in round i, tile
+  // i*nwg + (w%8)*(nwg/8) + w/8: the workgroups of one XCD work on a contiguous run of tiles (same A rows,
+  // neighbouring W panels) at the same time, so their operand panels hit in that XCD's L2.
+  const int nwg = gridDim.x, w = blockIdx.x;
+  const int wslot = (nwg % 8 == 0 && !(p.flags & UG_F_NOXCD)) ? (w % 8) * (nwg / 8) + w / 8 : w;
+  const int my_tiles = (ntiles - wslot + nwg - 1) / nwg;     // tiles wslot, wslot+nwg, ...
+  const int total_it = my_tiles * nk;
+
+  // ---- loader state for the tile currently being fetched ----
+  int a_lc[AI]; bool a_ok[AI]; const f16* a_ptr[AI]; int a_t[AI], a_y[AI], a_x[AI];
+  int a_pix[AI]; unsigned a_mask[AI];   // fast conv path: pixel index of tap (0,0,0) and per-tap validity bits
+  const bool fastconv = CONV && UNI && p.ups == 1;
+  int b_lc[BI]; const f16* b_ptr[BI]; bool b_ok[BI];
+#pragma unroll
+  for (int j = 0; j < AI; ++j) a_lc[j] = pc ^ swz<BK>((wave * AI + j) * RPI + lrow);
+#pragma unroll
+  for (int j = 0; j < BI; ++j) b_lc[j] = pc ^ swz<BK>((wave * BI + j) * RPI + lrow);
+
+  auto setup_tile = [&](int tile) {
+    const int tn = tile % ntn, tm = tile / ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+      const int m = m0 + (wave * AI + j) * RPI + lrow;
+      a_ok[j] = m < p.M;
+      if (CONV) {
+        const int hw = p.Ho * p.Wo;
+        const int t = m / hw, rem = m - t * hw;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        a_t[j] = t; a_y[j] = oy * p.stride - p.pad_t; a_x[j] = ox * p.stride - p.pad_l;
+        a_ptr[j] = nullptr;
+        if (fastconv) {
+          unsigned mk = 0; int bit = 0;
+          for (int it = 0; it < p.kt; ++it)
+            for (int iy = 0; iy < p.ky; ++iy)
+              for (int ix = 0; ix < p.kx; ++ix, ++bit) {
+                const int tt = t + it - (p.kt >> 1), y = a_y[j] + iy, x = a_x[j] + ix;
+                if (tt >= 0 && tt < p.T && y >= 0 && y < p.Hi && x >= 0 && x < p.Wi) mk |= 1u << bit;
+              }
+          a_mask[j] = a_ok[j] ? mk : 0u;
+          a_pix[j] = ((t - (p.kt >> 1)) * p.Hi + a_y[j]) * p.Wi + a_x[j];
+        }
+      } else {
+        a_ptr[j] = A0 + (long)m * p.C0;
+        a_t[j] = a_y[j] = a_x[j] = 0;
+      }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < BI; ++j) {   // LDS row lr holds W row n0 + perm(lr)
+      const int lr = (wave * BI + j) * RPI + lrow;
+      const int part = lr / WTN, rem = lr % WTN;
+      const int jj = rem >> 4, i = rem & 15;
+      const int n = n0 + part * WTN + (i >> 2) * WID + jj * 4 + (i & 3);
+      b_ok[j] = n < p.N;
+      b_ptr[j] = Wb + (long)n * p.ldw;
+    }
+  };
+
+  int ld_ti = 0, ld_ks = 0, ld_slot = 0;         // loader position: tile index (of this workgroup), K-step, ring slot
+  int u_it = 0, u_iy = 0, u_ix = 0, u_cb = 0;   // UNI conv: tap (t,y,x) and channel base of the next staged K tile
+  auto stage = [&](int kt0, int buf) {
+    f16* As = smem + buf * STAGE;
+    f16* Bs = As + BM * BK;
+    int it = 0, iy = 0, ix = 0, cb = 0;
+    if (CONV && UNI) {  // whole K tile sits inside one tap
+      if (ld_ks == 0) {   // first K tile of a tile: decode once (split-K may start mid-way)
+        const int tap = kt0 / Cin;
+        u_cb = kt0 - tap * Cin;
+        u_it = tap / (p.ky * p.kx);
+        const int r2 = tap - u_it * (p.ky * p.kx);
+        u_iy = r2 / p.kx; u_ix = r2 - u_iy * p.kx;
+      }
+      it = u_it; iy = u_iy; ix = u_ix; cb = u_cb;
+      if (fastconv) {
+        // every lane: source = base + (row pixel + uniform tap pixel offset) * C + channel, or the zero page
+        const int tapbit = (it * p.ky + iy) * p.kx + ix;
+        const int tappix = (it * p.Hi + iy) * p.Wi + ix;
+        const bool src0 = cb < p.C0;               // C0 % BK == 0 is checked by the launcher: a K tile never straddles
+        const f16* base = src0 ? A0 : p.A1;
+        const int Cs = src0 ? p.C0 : p.C1, c0 = src0 ? cb : cb - p.C0;
+#pragma unroll
+        for (int j = 0; j < AI; ++j) {
+          const bool ok = (a_mask[j] >> tapbit) & 1u;
+          const f16* src = ok ? base + ((long)(a_pix[j] + tappix) * Cs + c0 + a_lc[j] * 8) : p.zero;
+          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (wave * AI + j) * RPI * BK), 16, 0, 0);
+        }
+      }
+      u_cb += BK;
+      if (u_cb >= Cin) { u_cb = 0; if (++u_ix == p.kx) { u_ix = 0; if (++u_iy == p.ky) { u_iy = 0; ++u_it; } } }
+    }
+    if (!fastconv)
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
       const f16* src = p.zero;
       const int k = kt0 + a_lc[j] * 8;
       if (a_ok[j] && k < p.K) {
@@ -126,79 +210,105 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
           }
         }
       }
-      __builtin_amdgcn_global_load_lds((gptr_t)src,
-                                       (lptr_t)(As + buf * (BM * BK) + (wave * 4 + j) * 8 * BK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (wave * AI + j) * RPI * BK), 16, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
+    for (int j = 0; j < BI; ++j) {
       const int k = kt0 + b_lc[j] * 8;
-      const f16* src = (b_ok[j] && k < p.K) ? (b_ptr[j] + k) : p.zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)src,
-                                       (lptr_t)(Bs + buf * (BN * BK) + (wave * NT + j) * 8 * BK), 16, 0, 0);
+      const f16* src = (b_ok[j] && k < p.K && kt0 < kt_hi * BK) ? (b_ptr[j] + k) : p.zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (wave * BI + j) * RPI * BK), 16, 0, 0);
     }
   };
+  // fetch the next flat iteration (tile ld_ti of this workgroup, K-step ld_ks) into ring slot ld_slot
+  auto issue = [&]() {
+    if (ld_ks == 0) setup_tile(wslot + ld_ti * nwg);
+    stage((kt_lo + ld_ks) * BK, ld_slot);
+    if (++ld_ks == nk) { ld_ks = 0; ++ld_ti; }
+    if (++ld_slot == NST) ld_slot = 0;
+  };
 
-  f32x4 acc[4][NT];
+  f32x4 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + BK - 1) / BK;
   const int l15 = lane & 15, g = lane >> 4;
-  const int sw = l15 >> 1;  // read-side swizzle term: rows are (multiple of 16) + l15
+  const int sw = swz<BK>(l15);   // rows are (multiple of 16) + l15 and swz only looks at the low 4 row bits
+  const bool geglu = (p.flags & UG_F_GEGLU) != 0;
+  const bool of32 = (p.flags & UG_F_OUT_F32) != 0;
+  const int Nout = geglu ? p.N / 2 : p.N;
+  const int OW = geglu ? WID / 2 : WID;        // output columns of this lane
 
-  stage(0, 0);
-  int buf = 0;
-  for (int t = 0; t < nk; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < nk) stage((t + 1) * BK, buf ^ 1);
-    const f16* Ab = As + buf * (BM * BK) + (wm * 64 + l15) * BK;
-    const f16* Bb = Bs + buf * (BN * BK) + (wn * (BN / 2) + l15) * BK;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+  for (int s0 = 0; s0 < NST - 1; ++s0)
+    if (s0 < total_it) issue();
+  bool drain = false;   // after an epilogue the in-flight count also holds its loads/stores: drain once
+  int cp_ti = 0, cp_ks = 0, cp_slot = 0;
+  for (int fi = 0; fi < total_it; ++fi) {
+    // wait for the loads of iteration fi (issued NST-1 iterations ago); up to NST-2 younger fetches stay in flight
+    const int younger = min(NST - 2, total_it - 1 - fi);
+    if (drain || younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AI + BI)) : "memory");
+    drain = false;
+    __builtin_amdgcn_s_barrier();    // raw barrier: does not drain the LDS-DMA queue
+    asm volatile("" ::: "memory");   // keep this iteration's LDS reads / DMA issues below the barrier
+    if (fi + NST - 1 < total_it) issue();   // overwrites the slot every wave finished reading last iteration
+    const f16* Ab = smem + cp_slot * STAGE + (wm * WTM + l15) * BK;
+    const f16* Bb = smem + cp_slot * STAGE + BM * BK + (wn * WTN + l15) * BK;
+    if (++cp_slot == NST) cp_slot = 0;
+#pragma unroll
+    for (int kk = 0; kk < BK / 32; ++kk) {
       const int ch = ((kk * 4 + g) ^ sw) * 8;
-      f16x8 af[4], bf[NT];
+      f16x8 af[MT], bf[NT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(Ab + i * 16 * BK + ch);
+      for (int i = 0; i < MT; ++i) af[i] = *(const f16x8*)(Ab + i * 16 * BK + ch);
 #pragma unroll
       for (int j = 0; j < NT; ++j) bf[j] = *(const f16x8*)(Bb + j * 16 * BK + ch);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
     }
-    buf ^= 1;
-  }
+    if (++cp_ks != nk) continue;
+    cp_ks = 0;
+    const int ti = cp_ti++;
 
-  // ---- epilogue: lane holds WID contiguous columns of row m ----
-  const int nb = n0 + wn * (BN / 2) + g * WID;
-  const bool geglu = (p.flags & UG_F_GEGLU) != 0;
-  const bool of32 = (p.flags & UG_F_OUT_F32) != 0;
-  const int Nout = geglu ? p.N / 2 : p.N;
-  const int ob = geglu ? nb / 2 : nb;          // first output column of this lane
-  const int OW = geglu ? WID / 2 : WID;        // output columns of this lane
-  const bool full = (nb + WID <= p.N);
-  const bool vec = full && ((p.ldo & 7) == 0) && (!p.R1 || (p.ldr1 & 7) == 0) &&
-                   (!p.R2 || (p.ldr2 & 7) == 0) && (OW % 8 == 0);
+    // ---- tile finished: epilogue (the next tile's operands keep streaming into the ring meanwhile) ----
+    drain = true;
+    const int tile = wslot + ti * nwg;
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    const int nb = n0 + wn * WTN + g * WID;      // lane holds WID contiguous columns of its rows
+    if (p.splitk > 1) {   // raw fp32 partials [split][M][N]
+      float* P = p.partial + ((long)blockIdx.y * p.M) * p.N;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + l15;
-    if (m >= p.M) continue;
-    float v[WID];
+      for (int i = 0; i < MT; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + l15;
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j) {
+          const int n = nb + j * 4;
+          if (m < p.M && n + 4 <= p.N) *(f32x4*)(P + (long)m * p.N + n) = acc[i][j];
+          acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      continue;
+    }
+    const int ob = geglu ? nb / 2 : nb;          // first output column of this lane
+    const bool full = (nb + WID <= p.N);
+    const bool vec = full && ((p.ldo & 7) == 0) && (!p.R1 || (p.ldr1 & 7) == 0) &&
+                     (!p.R2 || (p.ldr2 & 7) == 0) && (OW % 8 == 0);
+    float bv[WID];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r];
+    for (int e = 0; e < WID; ++e) bv[e] = 0.f;
     if (full) {
       if (p.bias) {
 #pragma unroll
         for (int e = 0; e < WID; e += 8) {
           const f16x8 b = *(const f16x8*)(p.bias + nb + e);
 #pragma unroll
-          for (int q = 0; q < 8; ++q) v[e + q] += (float)b[q];
+          for (int q = 0; q < 8; ++q) bv[e + q] += (float)b[q];
         }
       }
       if (p.bias2) {
@@ -206,105 +316,235 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
         for (int e = 0; e < WID; e += 8) {
           const f16x8 b = *(const f16x8*)(p.bias2 + nb + e);
 #pragma unroll
-          for (int q = 0; q < 8; ++q) v[e + q] += (float)b[q];
+          for (int q = 0; q < 8; ++q) bv[e + q] += (float)b[q];
         }
       }
     } else {
 #pragma unroll
       for (int e = 0; e < WID; ++e)
         if (nb + e < p.N) {
-          if (p.bias) v[e] += (float)p.bias[nb + e];
-          if (p.bias2) v[e] += (float)p.bias2[nb + e];
+          if (p.bias) bv[e] += (float)p.bias[nb + e];
+          if (p.bias2) bv[e] += (float)p.bias2[nb + e];
         }
     }
-    if (geglu) {
-      if (WID == 16) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * gelu_f(v[8 + e]);
-      }
-    }
-    if (vec) {
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * WTM + i * 16 + l15;
+      float v[WID];
 #pragma unroll
-      for (int e = 0; e < OW; e += 8) {
-        float o[8];
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] = p.c0 * v[e + q];
-        if (p.R1) {
-          const f16x8 r = *(const f16x8*)(p.R1 + (long)m * p.ldr1 + ob + e);
+        for (int r = 0; r < 4; ++r) { v[j * 4 + r] = acc[i][j][r] + bv[j * 4 + r]; }
 #pragma unroll
-          for (int q = 0; q < 8; ++q) o[q] += p.c1 * (float)r[q];
-        }
-        if (p.R2) {
-          const f16x8 r = *(const f16x8*)(p.R2 + (long)m * p.ldr2 + ob + e);
+      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (m >= p.M) continue;
+      if (geglu) {
+        if (WID == 16) {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) o[q] += p.c2 * (float)r[q];
-        }
-        if (p.act == UG_ACT_SILU) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) o[q] = silu_f(o[q]);
-        } else if (p.act == UG_ACT_GELU) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) o[q] = gelu_f(o[q]);
-        }
-        if (of32) {
-          float* O = (float*)p.Out + out_off + (long)m * p.ldo + ob + e;
-          *(f32x4*)O = (f32x4){o[0], o[1], o[2], o[3]};
-          *(f32x4*)(O + 4) = (f32x4){o[4], o[5], o[6], o[7]};
-        } else {
-          f16x8 h;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) h[q] = (f16)o[q];
-          *(f16x8*)((f16*)p.Out + out_off + (long)m * p.ldo + ob + e) = h;
+          for (int e = 0; e < 8; ++e) v[e] = v[e] * gelu_f(v[8 + e]);
         }
       }
-    } else {
+      if (vec) {
 #pragma unroll
-      for (int e = 0; e < OW; ++e) {
-        const int n = ob + e;
-        if (n < Nout) {
-          float o = p.c0 * v[e];
-          if (p.R1) o += p.c1 * (float)p.R1[(long)m * p.ldr1 + n];
-          if (p.R2) o += p.c2 * (float)p.R2[(long)m * p.ldr2 + n];
-          if (p.act == UG_ACT_SILU) o = silu_f(o);
-          else if (p.act == UG_ACT_GELU) o = gelu_f(o);
-          if (of32) ((float*)p.Out)[out_off + (long)m * p.ldo + n] = o;
-          else ((f16*)p.Out)[out_off + (long)m * p.ldo + n] = (f16)o;
+        for (int e = 0; e < OW; e += 8) {
+          float o[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) o[q] = p.c0 * v[e + q];
+          if (p.R1) {
+            const f16x8 r = *(const f16x8*)(p.R1 + (long)m * p.ldr1 + ob + e);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] += p.c1 * (float)r[q];
+          }
+          if (p.R2) {
+            const f16x8 r = *(const f16x8*)(p.R2 + (long)m * p.ldr2 + ob + e);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] += p.c2 * (float)r[q];
+          }
+          if (p.act == UG_ACT_SILU) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] = silu_f(o[q]);
+          } else if (p.act == UG_ACT_GELU) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] = gelu_f(o[q]);
+          }
+          if (of32) {
+            float* O = (float*)p.Out + out_off + (long)m * p.ldo + ob + e;
+            *(f32x4*)O = (f32x4){o[0], o[1], o[2], o[3]};
+            *(f32x4*)(O + 4) = (f32x4){o[4], o[5], o[6], o[7]};
+          } else {
+            f16x8 h;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) h[q] = (f16)o[q];
+            *(f16x8*)((f16*)p.Out + out_off + (long)m * p.ldo + ob + e) = h;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < OW; ++e) {
+          const int n = ob + e;
+          if (n < Nout) {
+            float o = p.c0 * v[e];
+            if (p.R1) o += p.c1 * (float)p.R1[(long)m * p.ldr1 + n];
+            if (p.R2) o += p.c2 * (float)p.R2[(long)m * p.ldr2 + n];
+            if (p.act == UG_ACT_SILU) o = silu_f(o);
+            else if (p.act == UG_ACT_GELU) o = gelu_f(o);
+            if (of32) ((float*)p.Out)[out_off + (long)m * p.ldo + n] = o;
+            else ((f16*)p.Out)[out_off + (long)m * p.ldo + n] = (f16)o;
+          }
         }
       }
     }
   }
 }
 
-template <int BN, bool CONV, bool UNI>
-static void launch_t(const GemmP& p, int batch, hipStream_t s) {
-  const int ntm = cdiv(p.M, BM), ntn = cdiv(p.N, BN);
-  const size_t lds = (size_t)2 * (BM * BK + BN * BK) * sizeof(f16);
-  dim3 grid(ntm * ntn, 1, batch);
-  hipLaunchKernelGGL((gemm_kernel<BN, CONV, UNI>), grid, dim3(256), lds, s, p);
+// Sum the split-K partials in split order (deterministic) and apply the epilogue; 8 columns per thread.
+__global__ __launch_bounds__(256) void splitk_epilogue(const GemmP p) {
+  const long nvec = (long)p.M * (p.N / 8);
+  const int npr = p.N / 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < nvec; idx += (long)gridDim.x * blockDim.x) {
+    const long m = idx / npr; const int n = (int)(idx - m * npr) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.splitk; ++s) {
+      const float* P = p.partial + ((long)s * p.M + m) * p.N + n;
+      const f32x4 a = *(const f32x4*)P, b = *(const f32x4*)(P + 4);
+      v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3]; v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
+    }
+    if (p.bias) { const f16x8 b = *(const f16x8*)(p.bias + n);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] += (float)b[q]; }
+    if (p.bias2) { const f16x8 b = *(const f16x8*)(p.bias2 + n);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] += (float)b[q]; }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] *= p.c0;
+    if (p.R1) { const f16x8 r = *(const f16x8*)(p.R1 + m * p.ldr1 + n);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] += p.c1 * (float)r[q]; }
+    if (p.R2) { const f16x8 r = *(const f16x8*)(p.R2 + m * p.ldr2 + n);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] += p.c2 * (float)r[q]; }
+    if (p.act == UG_ACT_SILU) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = silu_f(v[q]);
+    } else if (p.act == UG_ACT_GELU) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = gelu_f(v[q]);
+    }
+    f16x8 h;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) h[q] = (f16)v[q];
+    *(f16x8*)((f16*)p.Out + m * p.ldo + n) = h;
+  }
 }
 
-void launch_gemm(const GemmP& p, int batch, hipStream_t s) {
+int gemm_knobs_get();
+template <int BM, int BN, int BK, int NST, int WMW, int WNW, bool CONV, bool UNI>
+static void launch_t(const GemmP& p, int batch, hipStream_t s) {
+  const int ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
+  const size_t lds = (size_t)NST * (BM + BN) * BK * sizeof(f16);
+  auto kern = gemm_kernel<BM, BN, BK, NST, WMW, WNW, CONV, UNI>;
+  static int per_cu = 0;
+  if (!per_cu) {
+    if (lds > 64 * 1024) UG_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    per_cu = GemmOcc<BM, BN, BK, NST, WMW, WNW>::wg;
+  }
+  const int split = p.splitk > 1 ? p.splitk : 1;
+  // persistent grid: at most (co-resident workgroups per CU) x 256 CUs, shared with the other grid dimensions
+  int gx = std::max(8, (per_cu * 256) / (split * batch));
+  gx = (gx / 8) * 8;
+  gx = std::min(gx, ntiles);
+  if (gemm_knobs_get() & 1) gx = ntiles;
+  dim3 grid(gx, split, batch);
+  hipLaunchKernelGGL(kern, grid, dim3(WMW * WNW * 64), lds, s, p);
+}
+
+template <int BM, int BN, int BK, int NST, int WMW, int WNW>
+static void launch_mode(const GemmP& p, int batch, hipStream_t s) {
+  if (p.conv) {
+    const bool uni = ((p.C0 + p.C1) % BK) == 0 && (p.C0 % BK) == 0 && p.kt * p.ky * p.kx <= 32;
+    if (uni) launch_t<BM, BN, BK, NST, WMW, WNW, true, true>(p, batch, s);
+    else launch_t<BM, BN, BK, NST, WMW, WNW, true, false>(p, batch, s);
+  } else {
+    launch_t<BM, BN, BK, NST, WMW, WNW, false, false>(p, batch, s);
+  }
+}
+
+// Tile configurations.  id -> (BM, BN, BK, stages, waves M x N, LDS)
+static void launch_cfg(int cfg, const GemmP& p, int batch, hipStream_t s) {
+  switch (cfg) {
+    case 0: launch_mode<128, 128, 64, 2, 2, 2>(p, batch, s); break;   //  64 KiB, 2 WG/CU
+    case 1: launch_mode<128, 64, 64, 2, 2, 2>(p, batch, s); break;    //  48 KiB, 3 WG/CU
+    case 2: launch_mode<128, 128, 64, 3, 2, 2>(p, batch, s); break;   //  96 KiB, 1 WG/CU
+    case 3: launch_mode<128, 64, 64, 3, 2, 2>(p, batch, s); break;    //  72 KiB, 2 WG/CU
+    case 4: launch_mode<256, 128, 64, 3, 4, 2>(p, batch, s); break;   // 144 KiB, 1 WG/CU (8 waves)
+    case 5: launch_mode<128, 128, 32, 4, 2, 2>(p, batch, s); break;   //  64 KiB, 2 WG/CU
+    case 6: launch_mode<256, 256, 32, 3, 4, 2>(p, batch, s); break;   //  96 KiB, 1 WG/CU (8 waves)
+    case 7: launch_mode<256, 128, 32, 4, 4, 2>(p, batch, s); break;   //  96 KiB, 1 WG/CU (8 waves)
+    case 8: launch_mode<256, 128, 64, 2, 4, 2>(p, batch, s); break;   //  96 KiB, 1 WG/CU (8 waves)
+    case 9: launch_mode<128, 128, 32, 3, 2, 2>(p, batch, s); break;   //  48 KiB, 3 WG/CU
+    default: UG_REQUIRE(false, "unknown GEMM tile config");
+  }
+}
+
+static int g_force_cfg = -1, g_force_split = -1, g_knobs = 0;   // knobs: 1 = one tile per workgroup, 2 = no XCD remap
+void gemm_force(int cfg, int split) { if (cfg <= -100) { g_knobs = -cfg - 100; return; } g_force_cfg = cfg; g_force_split = split; }
+
+
+
+int gemm_knobs_get() { return g_knobs; }
+
+// heuristic (measured on MI355X with tools/tune_gemm.py): returns tile config and split-K factor
+//   cfg 1 (128x64x64, 3 WG/CU)  : N < 2048 dense (short K, narrow N: more co-resident workgroups hide the
+//                                 per-tile prologue/epilogue) and the UNet-level convolutions
+//   cfg 0 (128x128x64, 2 WG/CU) : wide dense (GEGLU projections, CLIP MLP), the VAE's big convolutions, split-K
+void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
+  const bool geglu = p.flags & UG_F_GEGLU;
+  int cfg;
+  if (geglu) cfg = 0;
+  else if (p.conv) cfg = (p.N % 128 != 0 || p.M < 90000) ? 1 : 0;
+  else cfg = (p.N >= 2048) ? 0 : 1;
+  int split = 1;
+  const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * batch;
+  const int nk = cdiv(p.K, 64);
+  const bool plain_epi = !geglu && !(p.flags & UG_F_OUT_F32) && batch == 1 && (p.N % 8 == 0) && (p.ldo % 8 == 0) &&
+                         (!p.R1 || p.ldr1 % 8 == 0) && (!p.R2 || p.ldr2 % 8 == 0);
+  if (plain_epi && tiles128 < 384 && nk >= 16 && p.N >= 128) {   // < ~0.75 waves of workgroups and a long K loop
+    split = (int)std::min<long>(8, std::max<long>(1, 768 / tiles128));
+    split = std::min(split, nk / 4);
+    if (split < 2) split = 1; else cfg = 0;
+  }
+  if (g_force_cfg >= 0) cfg = g_force_cfg;
+  if (g_force_split >= 0) split = plain_epi ? std::max(1, g_force_split) : 1;
+  *cfg_out = cfg; *split_out = split;
+}
+
+void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
+  GemmP p = p0;
+  if (g_knobs & 2) p.flags |= UG_F_NOXCD;
   UG_REQUIRE(p.K % 8 == 0, "GEMM K must be a multiple of 8");
   UG_REQUIRE(p.ldw % 8 == 0, "GEMM ldw must be a multiple of 8");
   UG_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "empty GEMM");
   UG_REQUIRE(p.zero != nullptr, "zero page missing");
   UG_REQUIRE(p.nb_inner >= 1, "nb_inner");
-  const bool geglu = p.flags & UG_F_GEGLU;
-  if (geglu) UG_REQUIRE(p.N % 128 == 0, "GEGLU GEMM needs N % 128 == 0");
-  // BN=64 when N is not a multiple of 128 but wastes less at 64 (e.g. 320, 4, 8)
-  const bool bn64 = !geglu && (cdiv(p.N, 64) * 64 < cdiv(p.N, 128) * 128);
+  if (p.flags & UG_F_GEGLU) UG_REQUIRE(p.N % 128 == 0, "GEGLU GEMM needs N % 128 == 0");
   if (p.conv) {
-    const int Cin = p.C0 + p.C1;
     UG_REQUIRE(p.C0 % 8 == 0 && p.C1 % 8 == 0, "conv channel counts must be multiples of 8");
-    UG_REQUIRE(p.K == Cin * p.kt * p.ky * p.kx, "conv K mismatch");
+    UG_REQUIRE(p.K == (p.C0 + p.C1) * p.kt * p.ky * p.kx, "conv K mismatch");
     UG_REQUIRE(p.M == p.T * p.Ho * p.Wo, "conv M mismatch");
     UG_REQUIRE(p.ups == 1 || p.ups == 2, "ups");
-    const bool uni = (Cin % BK) == 0;
-    if (bn64) { if (uni) launch_t<64, true, true>(p, batch, s); else launch_t<64, true, false>(p, batch, s); }
-    else      { if (uni) launch_t<128, true, true>(p, batch, s); else launch_t<128, true, false>(p, batch, s); }
   } else {
     UG_REQUIRE(p.C0 % 8 == 0, "dense lda must be a multiple of 8");
-    if (bn64) launch_t<64, false, false>(p, batch, s); else launch_t<128, false, false>(p, batch, s);
+  }
+  int cfg = p.cfg_p1 - 1, split = p.splitk;
+  if (cfg < 0 || split < 1) { int c2, s2; gemm_plan(p, batch, &c2, &s2); if (cfg < 0) cfg = c2; if (split < 1) split = s2; }
+  if (p.flags & UG_F_GEGLU) UG_REQUIRE(cfg == 0 || cfg == 2 || cfg == 4 || cfg == 5 || cfg == 7 || cfg == 8 || cfg == 9, "GEGLU needs a 64-column wave tile");
+  p.splitk = split;
+  if (split > 1) UG_REQUIRE(p.partial != nullptr, "split-K needs a partial buffer");
+  launch_cfg(cfg, p, batch, s);
+  if (split > 1) {
+    const long nvec = (long)p.M * (p.N / 8);
+    int grid = (int)std::min<long>((nvec + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(splitk_epilogue, dim3(grid), dim3(256), 0, s, p);
   }
   UG_CHECK(hipGetLastError());
 }

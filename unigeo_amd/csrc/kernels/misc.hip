@@ -61,6 +61,17 @@ void launch_fill_f16(f16* p, float v, long n, hipStream_t s) {
   hipLaunchKernelGGL(k_fill, gs_grid(n), dim3(256), 0, s, p, v, n);
 }
 
+__global__ void k_fill_random(f16* p, long n, unsigned seed) {
+  GS_LOOP(i, n) {
+    unsigned h = (unsigned)i * 2654435761u ^ (seed * 0x9E3779B9u);
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    p[i] = (f16)((float)(h & 0xffff) / 32768.0f - 1.0f);
+  }
+}
+void launch_fill_random(f16* p, long n, unsigned seed, hipStream_t s) {
+  hipLaunchKernelGGL(k_fill_random, gs_grid(n), dim3(256), 0, s, p, n, seed);
+}
+
 __global__ void k_add_rowvec(const f16* x, const f16* vec, f16* y, long M, int C, int rpv) {
   const long n = M * (C / 8);
   const int nv = C / 8;

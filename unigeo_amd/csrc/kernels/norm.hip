@@ -87,33 +87,41 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats(const GroupNormP p, int n
   }
 }
 
-__global__ void gn_finalize(const GroupNormP p, int nchunk, float* ab) {
-  // grid (T); shared mean/rstd per group
-  __shared__ float mr[2 * 512];
-  const int C = p.C0 + p.C1, cpg = C / p.G;
-  const int t = blockIdx.x;
-  for (int g = threadIdx.x; g < p.G; g += blockDim.x) {
-    double a = 0.0, b = 0.0;
-    const int tlo = p.temporal ? 0 : t, thi = p.temporal ? p.T : t + 1;
-    for (int tt = tlo; tt < thi; ++tt)
-      for (int ch = 0; ch < nchunk; ++ch) {
-        const float* src = p.ws + (((long)tt * nchunk + ch) * p.G + g) * 2;
-        a += (double)src[0]; b += (double)src[1];
-      }
+__global__ __launch_bounds__(256) void gn_finalize(const GroupNormP p, int nchunk, float* ab) {
+  // grid (T), 256 threads: 256/G threads cooperate on one group's chunk partials (fp64, fixed order)
+  __shared__ double sa[256], sb[256];
+  __shared__ float mr[2 * 256];
+  const int C = p.C0 + p.C1, cpg = C / p.G, G = p.G;
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int SUB = 256 / G;
+  const int g = tid % G, sub = tid / G;
+  const int tlo = p.temporal ? 0 : t, thi = p.temporal ? p.T : t + 1;
+  const int nitem = (thi - tlo) * nchunk;
+  double a = 0.0, b = 0.0;
+  if (sub < SUB)
+    for (int it = sub; it < nitem; it += SUB) {
+      const int tt = tlo + it / nchunk, ch = it - (it / nchunk) * nchunk;
+      const float* src = p.ws + (((long)tt * nchunk + ch) * G + g) * 2;
+      a += (double)src[0]; b += (double)src[1];
+    }
+  sa[tid] = a; sb[tid] = b;
+  __syncthreads();
+  if (tid < G) {
+    for (int s2 = 1; s2 < SUB; ++s2) { a += sa[tid + s2 * G]; b += sb[tid + s2 * G]; }
     const double n = (double)cpg * p.HW * (p.temporal ? p.T : 1);
     const double mean = a / n;
     double var = b / n - mean * mean;
     if (var < 0.0) var = 0.0;
-    mr[2 * g] = (float)mean;
-    mr[2 * g + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    mr[2 * tid] = (float)mean;
+    mr[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const int g = c / cpg;
+  for (int c = tid; c < C; c += 256) {
+    const int gg = c / cpg;
     const float ga = p.gamma ? (float)p.gamma[c] : 1.f, be = p.beta ? (float)p.beta[c] : 0.f;
-    const float a = mr[2 * g + 1] * ga;
-    ab[((long)t * C + c) * 2 + 0] = a;
-    ab[((long)t * C + c) * 2 + 1] = be - mr[2 * g] * a;
+    const float sc = mr[2 * gg + 1] * ga;
+    ab[((long)t * C + c) * 2 + 0] = sc;
+    ab[((long)t * C + c) * 2 + 1] = be - mr[2 * gg] * sc;
   }
 }
 
@@ -173,7 +181,7 @@ size_t groupnorm_ws_floats(int T, int HW, int C, int G) {
 void launch_groupnorm(const GroupNormP& p, hipStream_t s) {
   const int C = p.C0 + p.C1;
   UG_REQUIRE(p.C0 % 8 == 0 && p.C1 % 8 == 0, "GroupNorm channels must be multiples of 8");
-  UG_REQUIRE(C % p.G == 0 && p.G <= 512, "GroupNorm group count");
+  UG_REQUIRE(C % p.G == 0 && p.G <= 256 && 256 % p.G == 0, "GroupNorm group count must divide 256");
   UG_REQUIRE(C <= GN_MAXV * GN_THREADS * 8, "GroupNorm too many channels");
   int nchunk, rpc;
   gn_chunks(p.HW, nchunk, rpc);
