@@ -1,0 +1,80 @@
+"""CPU: structural known-answers that pin the oracle / the product's weight manifests."""
+import dataclasses
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from unigeo_amd import weights as W
+
+
+def _sd_shapes(mod):
+    return {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+
+
+def test_manifests_match_oracle_modules_and_param_counts():
+    from oracle.clip import CLIPConfig, CLIPVisionWithProjection
+    from oracle.svd_unet import UNetConfig, UNetSpatioTemporal
+    from oracle.vae import AutoencoderKLTemporalDecoder, VAEConfig
+    with torch.device("meta"):
+        u, v, c = UNetSpatioTemporal(), AutoencoderKLTemporalDecoder(), CLIPVisionWithProjection()
+        assert _sd_shapes(u) == {k: tuple(s) for k, s in W.unet_manifest().items()}
+        assert _sd_shapes(v) == {k: tuple(s) for k, s in W.vae_manifest().items()}
+        assert _sd_shapes(c) == {k: tuple(s) for k, s in W.clip_manifest().items()}
+        tu, tv, tc = W.tiny_cfgs()
+        assert _sd_shapes(UNetSpatioTemporal(UNetConfig(**dataclasses.asdict(tu)))) == {k: tuple(s) for k, s in W.unet_manifest(tu).items()}
+        assert _sd_shapes(AutoencoderKLTemporalDecoder(VAEConfig(**dataclasses.asdict(tv)))) == {k: tuple(s) for k, s in W.vae_manifest(tv).items()}
+        assert _sd_shapes(CLIPVisionWithProjection(CLIPConfig(**dataclasses.asdict(tc)))) == {k: tuple(s) for k, s in W.clip_manifest(tc).items()}
+    n = lambda m: sum(int(np.prod(s)) for s in m.values())
+    assert n(W.unet_manifest()) == 1_524_623_082          # SVD-XT UNet: 1.52 B parameters (known answer)
+    assert n(W.clip_manifest()) == 632_076_800            # CLIP ViT-H/14 vision tower + projection
+    assert n(W.vae_manifest()) == 97_742_847
+
+
+def test_clip_oracle_matches_transformers():
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    from oracle.clip import CLIPConfig, CLIPVisionWithProjection
+    _, _, c = W.tiny_cfgs()
+    tc = CLIPVisionConfig(hidden_size=c.hidden_size, intermediate_size=c.intermediate_size,
+                          num_hidden_layers=c.num_hidden_layers, num_attention_heads=c.num_attention_heads,
+                          image_size=c.image_size, patch_size=c.patch_size, projection_dim=c.projection_dim, hidden_act="gelu")
+    torch.manual_seed(0)
+    ref = CLIPVisionModelWithProjection(tc).eval()
+    mine = CLIPVisionWithProjection(CLIPConfig(**dataclasses.asdict(c))).eval()
+    mine.load_state_dict({k: v for k, v in ref.state_dict().items() if "position_ids" not in k})
+    x = torch.randn(2, 3, 224, 224)
+    with torch.no_grad():
+        a, b = ref(pixel_values=x).image_embeds, mine(x)
+    assert float((a - b).abs().max()) < 1e-5
+
+
+def test_scheduler_closed_form_tables():
+    from oracle.scheduler import EulerKarrasVPred
+    for n in (2, 5, 25):
+        s = EulerKarrasVPred(); ts = s.set_timesteps(n)
+        sig = s.sigmas.numpy()
+        assert sig[0] == pytest.approx(700.0, rel=1e-6) and sig[n - 1] == pytest.approx(0.002, rel=1e-5) and sig[n] == 0
+        assert np.all(np.diff(sig) < 0)
+        np.testing.assert_allclose(ts.numpy(), 0.25 * np.log(sig[:n]), rtol=1e-6)
+        assert s.init_noise_sigma == pytest.approx(math.sqrt(700.0 ** 2 + 1), rel=1e-6)
+    # an exact denoiser (v-pred of a pure-noise sample around x0 = 0) is driven to 0 by the Euler steps
+    s = EulerKarrasVPred(); s.set_timesteps(5)
+    x = torch.randn(1000) * s.init_noise_sigma
+    for i in range(5):
+        sg = s.sigmas[i]
+        v = x / (sg * (sg ** 2 + 1) ** 0.5)                     # x0 = -s/sqrt(s^2+1)*v + x/(s^2+1) = 0
+        x = s.step(v, i, x)
+    assert float(x.abs().max()) < 1e-3
+
+
+def test_weight_loader_rejects_wrong_architecture():
+    u, _, _ = W.tiny_cfgs()
+    st = W.random_state(W.unet_manifest(u), 0)
+    W.check_against_manifest(st, W.unet_manifest(u), "unet")
+    bad = dict(st); bad.pop("conv_in.weight"); bad["surprise.weight"] = np.zeros(3, np.float16)
+    with pytest.raises(ValueError):
+        W.check_against_manifest(bad, W.unet_manifest(u), "unet")
+    bad = dict(st); bad["conv_in.weight"] = np.zeros((1, 2, 3, 3), np.float16)
+    with pytest.raises(ValueError):
+        W.check_against_manifest(bad, W.unet_manifest(u), "unet")

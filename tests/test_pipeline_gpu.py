@@ -1,0 +1,131 @@
+"""GPU: plugin surface, on-device normals, multi-GPU plumbing and full-size invariants, through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_goldens.npz"), allow_pickle=False)
+
+
+def _angle(a, b):
+    return np.degrees(np.arccos(np.clip((a * b).sum(-1), -1, 1)))
+
+
+def test_normals_kernel_vs_reference_golden(engine):
+    """G3: the reference's own prepare_output (lstsq in fp32).  The kernel solves the same 3x3 systems in fp64;
+    the reference's fp32 solve is itself noisy at cond(A^T A) ~ 1e5, so parity is on the angle: mean < 0.05 deg,
+    99.9th percentile < 1 deg, every normal unit length and facing the camera."""
+    got = engine.normals_from_depth(G["g3_depths"], G["g3_K"])
+    ref = G["g3_pred_normals"]
+    ang = _angle(got, ref)
+    assert np.isfinite(got).all()
+    assert ang.mean() < 0.05 and np.percentile(ang, 99.9) < 1.0, (ang.mean(), ang.max())
+    np.testing.assert_allclose(np.linalg.norm(got, axis=-1), 1.0, atol=1e-5)
+
+
+def test_normals_kernel_vs_oracle_full_frame(engine):
+    from oracle.geometry import prepare_output
+    from unigeo_amd.synthetic import synthetic_clip
+    H, W = 384, 512
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    d = (3.0 + np.sin(xx / 50.0) * np.cos(yy / 37.0) + 0.003 * yy).astype(np.float32)
+    K = synthetic_clip(1, H, W)["intrinsics"][0]
+    got = engine.normals_from_depth(d[None], K[None])
+    _, ref = prepare_output([d], [K])
+    ang = _angle(got[0], ref[0].numpy())
+    assert ang.mean() < 0.2 and np.percentile(ang, 99) < 2.0, (ang.mean(), np.percentile(ang, 99))
+
+
+@pytest.fixture(scope="module")
+def tiny_plugin():
+    from unigeo_amd import weights as W
+    from unigeo_amd.model import DepthCrafter
+    m = DepthCrafter(synthetic_weights=True, cfgs=W.tiny_cfgs(), num_inference_steps=2, workspace_bytes=3 << 30)
+    yield m
+    m.pipeline.engine.close()
+
+
+def test_plugin_contract(tiny_plugin):
+    """forward(data) -> {'pred_depths' [Nf,H,W], 'pred_normals' [Nf,H,W,3]} CPU float32 tensors
+    (reference model/depthcrafter.py:62-68), depth range of 1/(x+0.1) with x in [0,1]."""
+    from unigeo_amd.synthetic import synthetic_clip
+    data = synthetic_clip(3, 64, 128, seed=3)
+    out = tiny_plugin.forward(data)
+    d, n = out["pred_depths"], out["pred_normals"]
+    assert d.shape == (3, 64, 128) and n.shape == (3, 64, 128, 3)
+    assert d.dtype == torch.float32 and n.dtype == torch.float32 and d.device.type == "cpu"
+    assert torch.isfinite(d).all() and torch.isfinite(n).all()
+    assert float(d.min()) >= 1 / 1.1 - 1e-5 and float(d.max()) <= 10.0 + 1e-4
+    assert float(d.max()) == pytest.approx(10.0, rel=1e-5) and float(d.min()) == pytest.approx(1 / 1.1, rel=1e-5)
+    np.testing.assert_allclose(n.norm(dim=-1).numpy(), 1.0, atol=1e-4)
+    out2 = tiny_plugin.forward(data)                      # same seed -> bit-identical (deterministic kernels)
+    assert torch.equal(out2["pred_depths"], d) and torch.equal(out2["pred_normals"], n)
+    with pytest.raises(ValueError):
+        tiny_plugin.forward(synthetic_clip(2, 60, 64))    # not a multiple of 64: rejected, not padded
+
+
+def test_harness_end_to_end_with_plugin(tiny_plugin, tmp_path):
+    from unigeo_amd.harness import SyntheticGeometryDataset, evaluate
+    cfg = {"root": "x", "h": 64, "w": 64, "clip_length": 3, "clip_overlap": 1,
+           "eval_depth": {"metric_names": ["Abs Rel", "delta < 1.25"]}, "eval_normal": {"metric_names": ["normal mean"]}}
+    ds = SyntheticGeometryDataset(clip_length=3, clip_overlap=1, input_size=(64, 64), num_frames=5)
+    rows, _ = evaluate(cfg, dataset=ds, model=tiny_plugin, save_dir=str(tmp_path), verbose=False)
+    assert len(rows) == 3 and all(np.isfinite(r["Abs Rel"]) and np.isfinite(r["normal mean"]) for r in rows)
+    assert (tmp_path / "metrics.csv").exists()
+
+
+def test_rccl_gather_of_engine_memory_zero_copy(tiny_plugin):
+    """The N>1 path hands engine-owned HIP memory to torch.distributed (RCCL).  With one GPU this checks the
+    zero-copy view and a world-size-1 nccl all_gather; the sharding logic itself is covered on CPU/gloo."""
+    import torch.distributed as dist
+    from unigeo_amd.shard import DeviceArray
+    from unigeo_amd.synthetic import synthetic_clip
+    tiny_plugin.forward(synthetic_clip(3, 64, 64, seed=1))
+    eng = tiny_plugin.pipeline.engine
+    ptr, shape = eng.device_ptrs()["depth"]
+    view = torch.as_tensor(DeviceArray(ptr, shape), device="cuda:0")
+    assert view.data_ptr() == ptr and tuple(view.shape) == shape
+    _, host, _ = eng.get_outputs(frames=False, depth=True)
+    assert np.array_equal(view.cpu().numpy(), host)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        out = [torch.empty_like(view)]
+        dist.all_gather(out, view)
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], view)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_full_size_invariants():
+    """BASELINE configs[1] geometry (25 x 384 x 512) with 1 Euler step: size-independent properties -
+    finite, in range, bit-reproducible run to run, and VAE-encode chunking changes the result by fp16 ulps only."""
+    from unigeo_amd.pipeline import DepthCrafterPipelineHIP, make_noise
+    from unigeo_amd.synthetic import synthetic_clip
+    from unigeo_amd.model.depthcrafter import DepthCrafter
+    pipe = DepthCrafterPipelineHIP.from_random(seed=42, workspace_bytes=40 << 30)
+    try:
+        T, H, W = 25, 384, 512
+        clip = synthetic_clip(T, H, W)
+        frames = DepthCrafter.prepare_input(None, clip)
+        nl, na = make_noise(T, H, W, 0)
+        r1 = pipe(frames, num_inference_steps=1, window_size=T, noise_latents=nl, noise_aug=na)
+        f1, d1 = r1.frames[0].copy(), r1.depth.copy()
+        assert f1.shape == (T, H, W, 3) and np.isfinite(f1).all() and f1.min() >= 0 and f1.max() <= 1
+        assert d1.min() >= 1 / 1.1 - 1e-5 and d1.max() <= 10 + 1e-4
+        r2 = pipe(frames, num_inference_steps=1, window_size=T, noise_latents=nl, noise_aug=na)
+        assert np.array_equal(r2.frames[0], f1) and np.array_equal(r2.depth, d1)
+        eng = pipe.engine
+        v = (frames[:9] * 2 - 1).astype(np.float32)
+        a = eng.vae_encode(v)
+        b = np.concatenate([eng.vae_encode(v[:4]), eng.vae_encode(v[4:])], 0)
+        # frames are independent in the encoder; chunking only changes reduction orders (GroupNorm partial sums,
+        # split-K), i.e. a few fp16 ulps - not bit-exact, exactly like cuDNN algorithm changes in the reference
+        assert_close(a, b, 5e-3, "VAE encode chunk invariance")
+    finally:
+        pipe.engine.close()

@@ -104,7 +104,8 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
   // ---- loader state for the tile currently being fetched ----
   int a_lc[AI]; bool a_ok[AI]; const f16* a_ptr[AI]; int a_t[AI], a_y[AI], a_x[AI];
   int a_pix[AI]; unsigned a_mask[AI];   // fast conv path: pixel index of tap (0,0,0) and per-tap validity bits
-  const bool fastconv = CONV && UNI && p.ups == 1;
+  const bool fastconv = CONV && UNI;
+  int a_par[AI];                        // ups == 2: parity bits (y&1)<<1 | (x&1) of the row's first tap in upsampled coords
   int b_lc[BI]; const f16* b_ptr[BI]; bool b_ok[BI];
 #pragma unroll
   for (int j = 0; j < AI; ++j) a_lc[j] = pc ^ swz<BK>((wave * AI + j) * RPI + lrow);
@@ -130,10 +131,16 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
             for (int iy = 0; iy < p.ky; ++iy)
               for (int ix = 0; ix < p.kx; ++ix, ++bit) {
                 const int tt = t + it - (p.kt >> 1), y = a_y[j] + iy, x = a_x[j] + ix;
-                if (tt >= 0 && tt < p.T && y >= 0 && y < p.Hi && x >= 0 && x < p.Wi) mk |= 1u << bit;
+                if (tt >= 0 && tt < p.T && y >= 0 && y < p.Hi * p.ups && x >= 0 && x < p.Wi * p.ups) mk |= 1u << bit;
               }
           a_mask[j] = a_ok[j] ? mk : 0u;
-          a_pix[j] = ((t - (p.kt >> 1)) * p.Hi + a_y[j]) * p.Wi + a_x[j];
+          if (p.ups == 1) {
+            a_pix[j] = ((t - (p.kt >> 1)) * p.Hi + a_y[j]) * p.Wi + a_x[j];
+            a_par[j] = 0;
+          } else {   // nearest-2x source: pixel of tap (iy,ix) = base + ((iy+py)>>1)*Wi + ((ix+px)>>1)
+            a_pix[j] = ((t - (p.kt >> 1)) * p.Hi + (a_y[j] >> 1)) * p.Wi + (a_x[j] >> 1);
+            a_par[j] = ((a_y[j] & 1) << 1) | (a_x[j] & 1);
+          }
         }
       } else {
         a_ptr[j] = A0 + (long)m * p.C0;
@@ -169,14 +176,16 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
       if (fastconv) {
         // every lane: source = base + (row pixel + uniform tap pixel offset) * C + channel, or the zero page
         const int tapbit = (it * p.ky + iy) * p.kx + ix;
-        const int tappix = (it * p.Hi + iy) * p.Wi + ix;
+        const int tappix = (it * p.Hi + iy) * p.Wi + ix;   // ups == 1
+        const int up2 = p.ups == 2;
         const bool src0 = cb < p.C0;               // C0 % BK == 0 is checked by the launcher: a K tile never straddles
         const f16* base = src0 ? A0 : p.A1;
         const int Cs = src0 ? p.C0 : p.C1, c0 = src0 ? cb : cb - p.C0;
 #pragma unroll
         for (int j = 0; j < AI; ++j) {
           const bool ok = (a_mask[j] >> tapbit) & 1u;
-          const f16* src = ok ? base + ((long)(a_pix[j] + tappix) * Cs + c0 + a_lc[j] * 8) : p.zero;
+          const int tp = up2 ? it * p.Hi * p.Wi + ((iy + (a_par[j] >> 1)) >> 1) * p.Wi + ((ix + (a_par[j] & 1)) >> 1) : tappix;
+          const f16* src = ok ? base + ((long)(a_pix[j] + tp) * Cs + c0 + a_lc[j] * 8) : p.zero;
           __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (wave * AI + j) * RPI * BK), 16, 0, 0);
         }
       }
@@ -508,7 +517,7 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
   const int nk = cdiv(p.K, 64);
   const bool plain_epi = !geglu && !(p.flags & UG_F_OUT_F32) && batch == 1 && (p.N % 8 == 0) && (p.ldo % 8 == 0) &&
                          (!p.R1 || p.ldr1 % 8 == 0) && (!p.R2 || p.ldr2 % 8 == 0);
-  if (plain_epi && tiles128 < 384 && nk >= 16 && p.N >= 128) {   // < ~0.75 waves of workgroups and a long K loop
+  if (plain_epi && tiles128 <= 128 && nk >= 16 && p.N >= 128) {   // under half a wave of workgroups and a long K loop
     split = (int)std::min<long>(8, std::max<long>(1, 768 / tiles128));
     split = std::min(split, nk / 4);
     if (split < 2) split = 1; else cfg = 0;

@@ -49,6 +49,24 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats(const GroupNormP p, int n
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s[k][e] = 0.f; q[k][e] = 0.f; }
   if (active) {
+    if (gg.vpt == 1) {   // common case: one vector per thread -> keep 4 rows' loads in flight
+      const int c = v0 * 8;
+      int r = r0 + rsub;
+      for (; r + 3 * gg.rpi < r1; r += 4 * gg.rpi) {
+        f16x8 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = gn_load(p, (long)t * p.HW + r + u * gg.rpi, c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float f = (float)x[u][e]; s[0][e] += f; q[0][e] += f * f; }
+      }
+      for (; r < r1; r += gg.rpi) {
+        const f16x8 x = gn_load(p, (long)t * p.HW + r, c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = (float)x[e]; s[0][e] += f; q[0][e] += f * f; }
+      }
+    } else
     for (int r = r0 + rsub; r < r1; r += gg.rpi) {
       const long m = (long)t * p.HW + r;
 #pragma unroll
@@ -98,12 +116,18 @@ __global__ __launch_bounds__(256) void gn_finalize(const GroupNormP p, int nchun
   const int tlo = p.temporal ? 0 : t, thi = p.temporal ? p.T : t + 1;
   const int nitem = (thi - tlo) * nchunk;
   double a = 0.0, b = 0.0;
-  if (sub < SUB)
-    for (int it = sub; it < nitem; it += SUB) {
-      const int tt = tlo + it / nchunk, ch = it - (it / nchunk) * nchunk;
-      const float* src = p.ws + (((long)tt * nchunk + ch) * G + g) * 2;
-      a += (double)src[0]; b += (double)src[1];
+  if (sub < SUB) {
+    // partial (tt, ch) lives at ((tt*nchunk + ch)*G + g)*2 and (tt, ch) pairs are contiguous in `it`
+    const float2* src = (const float2*)p.ws + (long)tlo * nchunk * G + g;
+    int it = sub;
+    for (; it + 3 * SUB < nitem; it += 4 * SUB) {      // 4 independent loads in flight, fixed summation order
+      const float2 v0 = src[(long)it * G], v1 = src[(long)(it + SUB) * G];
+      const float2 v2 = src[(long)(it + 2 * SUB) * G], v3 = src[(long)(it + 3 * SUB) * G];
+      a += (double)v0.x; b += (double)v0.y; a += (double)v1.x; b += (double)v1.y;
+      a += (double)v2.x; b += (double)v2.y; a += (double)v3.x; b += (double)v3.y;
     }
+    for (; it < nitem; it += SUB) { const float2 v = src[(long)it * G]; a += (double)v.x; b += (double)v.y; }
+  }
   sa[tid] = a; sb[tid] = b;
   __syncthreads();
   if (tid < G) {
@@ -146,6 +170,38 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply(const GroupNormP p, int r
       }
     }
   }
+  if (gg.vpt == 1) {
+    const int c = v0 * 8;
+    int r = r0 + rsub;
+    for (; r + 3 * gg.rpi < r1; r += 4 * gg.rpi) {
+      f16x8 x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = gn_load(p, (long)t * p.HW + r + u * gg.rpi, c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f16x8 y;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float f = (float)x[u][e] * a[0][e] + b[0][e];
+          if (p.silu) f = silu_f(f);
+          y[e] = (f16)f;
+        }
+        *(f16x8*)(p.Y + ((long)t * p.HW + r + u * gg.rpi) * C + c) = y;
+      }
+    }
+    for (; r < r1; r += gg.rpi) {
+      const f16x8 x = gn_load(p, (long)t * p.HW + r, c);
+      f16x8 y;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = (float)x[e] * a[0][e] + b[0][e];
+        if (p.silu) f = silu_f(f);
+        y[e] = (f16)f;
+      }
+      *(f16x8*)(p.Y + ((long)t * p.HW + r) * C + c) = y;
+    }
+    return;
+  }
   for (int r = r0 + rsub; r < r1; r += gg.rpi) {
     const long m = (long)t * p.HW + r;
 #pragma unroll
@@ -166,15 +222,21 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply(const GroupNormP p, int r
   }
 }
 
-static inline void gn_chunks(int HW, int& nchunk, int& rpc) {
-  rpc = 64;
+// rows per chunk: enough workgroups (T * nchunk >= ~1024) to fill 256 CUs several times over, but at
+// least 4 row-iterations per thread so the unrolled loads stay in flight; at most 128 chunks per frame.
+static inline void gn_chunks2(int T, int HW, int C, int& nchunk, int& rpc) {
+  const GnGeom gg = gn_geom(C);
+  const int want = cdiv(1024, T);                       // chunks per frame we would like
+  rpc = cdiv(HW, want);
+  const int min_rpc = 4 * gg.rpi;
+  if (rpc < min_rpc) rpc = min_rpc;
   nchunk = cdiv(HW, rpc);
-  if (nchunk > 96) { nchunk = 96; rpc = cdiv(HW, nchunk); nchunk = cdiv(HW, rpc); }
+  if (nchunk > 128) { nchunk = 128; rpc = cdiv(HW, nchunk); nchunk = cdiv(HW, rpc); }
 }
 
 size_t groupnorm_ws_floats(int T, int HW, int C, int G) {
   int nchunk, rpc;
-  gn_chunks(HW, nchunk, rpc);
+  gn_chunks2(T, HW, C, nchunk, rpc);
   return (size_t)T * nchunk * G * 2 + (size_t)T * C * 2;
 }
 
@@ -184,7 +246,7 @@ void launch_groupnorm(const GroupNormP& p, hipStream_t s) {
   UG_REQUIRE(C % p.G == 0 && p.G <= 256 && 256 % p.G == 0, "GroupNorm group count must divide 256");
   UG_REQUIRE(C <= GN_MAXV * GN_THREADS * 8, "GroupNorm too many channels");
   int nchunk, rpc;
-  gn_chunks(p.HW, nchunk, rpc);
+  gn_chunks2(p.T, p.HW, C, nchunk, rpc);
   const GnGeom gg = gn_geom(C);
   float* ab = p.ws + (size_t)p.T * nchunk * p.G * 2;
   const size_t lds = (size_t)gg.rpi * C * 2 * sizeof(float);

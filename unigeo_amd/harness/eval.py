@@ -1,0 +1,59 @@
+"""The evaluation loop - mirrors ``/root/reference/eval.py:10-99`` and ``configs/config_utils.py:3-35``.
+
+Differences kept deliberately small: the YAML path is an argument instead of being hard-coded (eval.py:11),
+dataset / model classes can be passed as objects, visualisation and the point-cloud / camera-pose branches
+(not produced by the DepthCrafter / StableNormal plugins) are not reproduced.
+"""
+import importlib
+import os
+
+from .io_utils import prepare_gt_label
+from .metrics import MetricsManager, depth_evaluation, normal_evaluation
+
+
+def import_class_from_module(module_name, class_name):
+    return getattr(importlib.import_module(module_name), class_name)
+
+
+def parse_dataset_config(config):
+    return {"root": config["root"], "clip_length": config.get("clip_length", 30),
+            "clip_overlap": config.get("clip_overlap", 0), "input_size": (config["h"], config["w"]),
+            "target_size": (config["h"], config["w"])}
+
+
+def parse_metric_config(config):
+    names = []
+    for key in ("eval_depth", "eval_pcd", "eval_camera", "eval_normal"):
+        if key in config:
+            names.extend(config[key]["metric_names"])
+    return names
+
+
+def evaluate(config, dataset=None, model=None, save_dir="./debug_output", rank=0, world=1, verbose=True):
+    """Run the reference's per-clip loop.  With ``world > 1`` this rank only evaluates clips
+    ``rank, rank+world, ...`` (clips are independent samples); rows are merged by the caller."""
+    if dataset is None:
+        dataset = import_class_from_module("unigeo_amd.harness.dataset", config["dataset"])(**parse_dataset_config(config))
+    if model is None:
+        model = import_class_from_module("unigeo_amd.model", config["model_name"])(**config["model_params"])
+    mm = MetricsManager(metric_names=parse_metric_config(config))
+    os.makedirs(save_dir, exist_ok=True)
+    save_path = os.path.join(save_dir, "metrics.csv")
+    rows = []
+    for data_idx in range(rank, len(dataset), world):
+        data = dataset[data_idx]
+        seq = f"{data_idx:03d}_{data['scene_name']}"
+        if verbose:
+            print("processing seq:", seq)
+        output = model.forward(data)
+        gt = prepare_gt_label(data)
+        metric = {"seq_name": seq}
+        if "eval_depth" in config:
+            res = depth_evaluation(output["pred_depths"], gt["gt_depths"], custom_mask=gt["gt_masks"], align_with_lstsq=True)
+            metric.update(res[0])
+        if "eval_normal" in config:
+            metric.update(normal_evaluation(output["pred_normals"], gt["gt_normals"], custom_mask=gt["gt_masks"]))
+        rows.append(metric)
+        mm.update_metrics(metric)
+        mm.export_to_csv(save_path)
+    return rows, mm
