@@ -491,6 +491,13 @@ static void launch_cfg(int cfg, const GemmP& p, int batch, hipStream_t s) {
     case 7: launch_mode<256, 128, 32, 4, 4, 2>(p, batch, s); break;   //  96 KiB, 1 WG/CU (8 waves)
     case 8: launch_mode<256, 128, 64, 2, 4, 2>(p, batch, s); break;   //  96 KiB, 1 WG/CU (8 waves)
     case 9: launch_mode<128, 128, 32, 3, 2, 2>(p, batch, s); break;   //  48 KiB, 3 WG/CU
+    case 10: launch_mode<128, 64, 32, 2, 2, 2>(p, batch, s); break;   //  24 KiB
+    case 11: launch_mode<128, 64, 32, 4, 2, 2>(p, batch, s); break;   //  48 KiB
+    case 12: launch_mode<64, 64, 64, 2, 2, 2>(p, batch, s); break;    //  32 KiB
+    case 13: launch_mode<64, 128, 64, 2, 2, 2>(p, batch, s); break;   //  48 KiB
+    case 14: launch_mode<256, 64, 64, 2, 4, 2>(p, batch, s); break;   //  80 KiB, 8 waves
+    case 15: launch_mode<256, 256, 64, 2, 2, 4>(p, batch, s); break;  // 128 KiB, 8 waves, wave tile 128x64
+    case 16: launch_mode<256, 256, 64, 2, 4, 2>(p, batch, s); break;  // 128 KiB, 8 waves, wave tile 64x128
     default: UG_REQUIRE(false, "unknown GEMM tile config");
   }
 }
@@ -505,13 +512,16 @@ int gemm_knobs_get() { return g_knobs; }
 // heuristic (measured on MI355X with tools/tune_gemm.py): returns tile config and split-K factor
 //   cfg 1 (128x64x64, 3 WG/CU)  : N < 2048 dense (short K, narrow N: more co-resident workgroups hide the
 //                                 per-tile prologue/epilogue) and the UNet-level convolutions
+//   cfg 14 (256x64x64, 8 waves) : the same shapes at the full-resolution UNet level (M = 76800)
+//   cfg 15 (256x256x64, 8 waves, 128x64 wave tiles) : wide outputs - GEGLU / N >= 2048 projections and the
+//                                 256/512-channel VAE convolutions (halves the LDS + L2 bytes per FLOP)
 //   cfg 0 (128x128x64, 2 WG/CU) : wide dense (GEGLU projections, CLIP MLP), the VAE's big convolutions, split-K
 void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
   const bool geglu = p.flags & UG_F_GEGLU;
   int cfg;
-  if (geglu) cfg = 0;
-  else if (p.conv) cfg = (p.N % 128 != 0 || p.M < 90000) ? 1 : 0;
-  else cfg = (p.N >= 2048) ? 0 : 1;
+  if (geglu) cfg = 15;
+  else if (p.conv) cfg = (p.M >= 90000 && p.N % 256 == 0) ? 15 : (p.M >= 90000 && p.N % 128 == 0) ? 0 : (p.M >= 50000 ? 14 : 1);
+  else cfg = (p.N >= 2048) ? 15 : (p.M >= 50000 ? 14 : 1);
   int split = 1;
   const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * batch;
   const int nk = cdiv(p.K, 64);
@@ -546,7 +556,7 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
   }
   int cfg = p.cfg_p1 - 1, split = p.splitk;
   if (cfg < 0 || split < 1) { int c2, s2; gemm_plan(p, batch, &c2, &s2); if (cfg < 0) cfg = c2; if (split < 1) split = s2; }
-  if (p.flags & UG_F_GEGLU) UG_REQUIRE(cfg == 0 || cfg == 2 || cfg == 4 || cfg == 5 || cfg == 7 || cfg == 8 || cfg == 9, "GEGLU needs a 64-column wave tile");
+  if (p.flags & UG_F_GEGLU) UG_REQUIRE(cfg == 0 || cfg == 2 || cfg == 4 || cfg == 5 || cfg == 7 || cfg == 8 || cfg == 9 || cfg == 13 || cfg == 15, "GEGLU needs a 64-column wave tile");
   p.splitk = split;
   if (split > 1) UG_REQUIRE(p.partial != nullptr, "split-K needs a partial buffer");
   launch_cfg(cfg, p, batch, s);
