@@ -267,19 +267,38 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
     const f16* Ab = smem + cp_slot * STAGE + (wm * WTM + l15) * BK;
     const f16* Bb = smem + cp_slot * STAGE + BM * BK + (wn * WTN + l15) * BK;
     if (++cp_slot == NST) cp_slot = 0;
+    {
+      // Fragment reads are software-pipelined inside the K-step: all reads of the first 32-deep slice are issued up
+      // front, the second slice's reads are interleaved under the first slice's MFMAs (order pinned below), so the
+      // LDS latency is exposed once per step instead of once per MFMA group.
+      constexpr int KK = BK / 32;
+      f16x8 af[KK][MT], bf[KK][NT];
 #pragma unroll
-    for (int kk = 0; kk < BK / 32; ++kk) {
-      const int ch = ((kk * 4 + g) ^ sw) * 8;
-      f16x8 af[MT], bf[NT];
+      for (int kk = 0; kk < KK; ++kk) {
+        const int ch = ((kk * 4 + g) ^ sw) * 8;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *(const f16x8*)(Ab + i * 16 * BK + ch);
+        for (int j = 0; j < NT; ++j) bf[kk][j] = *(const f16x8*)(Bb + j * 16 * BK + ch);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bf[j] = *(const f16x8*)(Bb + j * 16 * BK + ch);
+        for (int i = 0; i < MT; ++i) af[kk][i] = *(const f16x8*)(Ab + i * 16 * BK + ch);
+      }
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+      for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+      constexpr int R = MT + NT, Q = MT * NT;
+      __builtin_amdgcn_sched_group_barrier(0x100, R, 0);               // slice 0 reads
+      if (KK == 2) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          __builtin_amdgcn_sched_group_barrier(0x008, Q / R, 0);       // slice 0 MFMAs ...
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           // ... hiding slice 1 reads
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, Q - R * (Q / R), 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, Q, 0);
     }
     if (++cp_ks != nk) continue;
     cp_ks = 0;
@@ -520,8 +539,11 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
   const bool geglu = p.flags & UG_F_GEGLU;
   int cfg;
   if (geglu) cfg = 15;
-  else if (p.conv) cfg = (p.M >= 90000 && p.N % 256 == 0) ? 15 : (p.M >= 90000 && p.N % 128 == 0) ? 0 : (p.M >= 50000 ? 14 : 1);
-  else cfg = (p.N >= 2048) ? 15 : (p.M >= 50000 ? 14 : 1);
+  else if (p.conv)
+    cfg = ((p.M >= 90000 && p.N % 256 == 0) || (p.M >= 16384 && p.N >= 512)) ? 15
+          : (p.M >= 90000 && p.N % 128 == 0) ? 0 : (p.M >= 50000 ? 14 : 1);
+  else
+    cfg = (p.N >= 2048 || (p.M >= 16384 && p.N >= 512 && p.K >= 2048)) ? 15 : (p.M >= 50000 ? 14 : 1);
   int split = 1;
   const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * batch;
   const int nk = cdiv(p.K, 64);
