@@ -59,7 +59,66 @@ __device__ __forceinline__ void pv_block(const f16* vt, int kb, int lane, const 
 
 #define FA_KV 64
 
-__global__ __launch_bounds__(256) void flash_attn64_kernel(const FlashP p) {
+// One KV tile of 64 keys for a wave's 32 query rows.  MASK is only instantiated for the ragged last tile, so
+// the full tiles carry no compare/select work.  Scores stay unscaled in registers; the softmax scale (times
+// log2 e) is folded into the single FMA that feeds v_exp_f32.
+template <bool MASK>
+__device__ __forceinline__ void fa_tile(const f16* kt, const f16* vt, const f16x8 (&qf)[4], int lane, int kv0, int S,
+                                        float sc, float& m_run, float& l_run, f32x16 (&o)[2]) {
+  const int qi = lane & 31, hh = lane >> 5;
+  f32x16 s[2];
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f16x8 kf[2][4];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int row = kb * 32 + qi;   // lane's key row inside the tile
+#pragma unroll
+    for (int c = 0; c < 4; ++c) kf[kb][c] = *(const f16x8*)(kt + row * 64 + (((c * 2 + hh) ^ kswz(row)) * 8));
+  }
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][0], qf[0], zero16, 0, 0, 0);
+#pragma unroll
+    for (int c = 1; c < 4; ++c) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][c], qf[c], s[kb], 0, 0, 0);
+  }
+  float mx = -1e30f;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (MASK) {
+        const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (key >= S) s[kb][r] = -1e30f;
+      }
+      mx = fmaxf(mx, s[kb][r]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  const float m_new = fmaxf(m_run, mx * sc);          // running max in the scaled (log2) domain
+  if (!__all(m_new == m_run)) {                        // rescale only when some row's max moved (exact: alpha == 1 otherwise)
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    l_run *= alpha;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    m_run = m_new;
+  }
+  float pr[2][16];
+  float ps = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sc, -m_run));
+      pr[kb][r] = e;
+      ps += e;
+    }
+  l_run += ps;
+  pv_block(vt, 0, lane, pr[0], o);
+  pv_block(vt, 32, lane, pr[1], o);
+}
+
+__global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const FlashP p) {
   __shared__ __attribute__((aligned(16))) f16 lds[2 * 2 * FA_KV * 64];  // [buf][K|V][64][64]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,12 +146,11 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(const FlashP p) {
     for (int j = 0; j < 2; ++j) {
       const int r = srow0 + j * 8;
       const int key = kv0 + r;
-      const bool ok = key < p.S;
-      const f16* ks = ok ? p.K + (row0 + key) * p.ldk + h * 64 + ((pc ^ kswz(r)) * 8) : (const f16*)nullptr;
-      const f16* vs = ok ? p.V + (row0 + key) * p.ldv + h * 64 + ((pc ^ vswz(r)) * 8) : (const f16*)nullptr;
-      // out-of-range keys: re-read key 0 (always valid); their scores are masked below and
-      // their P is exactly 0, so the (finite) V rows they bring in contribute nothing.
-      if (!ok) { ks = p.K + row0 * p.ldk + h * 64 + pc * 8; vs = p.V + row0 * p.ldv + h * 64 + pc * 8; }
+      // out-of-range keys: re-read key 0 (always valid); their scores are masked and their P is exactly 0,
+      // so the (finite) V rows they bring in contribute nothing.
+      const long krow = key < p.S ? key : 0;
+      const f16* ks = p.K + (row0 + krow) * p.ldk + h * 64 + ((pc ^ kswz(r)) * 8);
+      const f16* vs = p.V + (row0 + krow) * p.ldv + h * 64 + ((pc ^ vswz(r)) * 8);
       __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(kd + (wave * 16 + j * 8) * 64), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)vs, (lptr_t)(vd + (wave * 16 + j * 8) * 64), 16, 0, 0);
     }
@@ -106,6 +164,7 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(const FlashP p) {
   float m_run = -1e30f, l_run = 0.f;
 
   const int ntile = (p.S + FA_KV - 1) / FA_KV;
+  const int nfull = p.S / FA_KV;
   stage(0, 0);
   int buf = 0;
   for (int t = 0; t < ntile; ++t) {
@@ -114,58 +173,8 @@ __global__ __launch_bounds__(256) void flash_attn64_kernel(const FlashP p) {
     if (t + 1 < ntile) stage((t + 1) * FA_KV, buf ^ 1);
     const f16* kt = lds + buf * (2 * FA_KV * 64);
     const f16* vt = kt + FA_KV * 64;
-    const int kv0 = t * FA_KV;
-
-    // S^T[key][q] for the two 32-key blocks
-    f32x16 s[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-      const int row = kb * 32 + qi;   // lane's key row inside the tile
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int chunk = (c * 2 + hh) ^ kswz(row);
-        const f16x8 kf = *(const f16x8*)(kt + row * 64 + chunk * 8);
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[c], s[kb], 0, 0, 0);
-      }
-    }
-    // scale (+ mask the key tail in the last tile)
-    float pr[2][16];
-    float mx = -1e30f;
-    const bool tail = (kv0 + FA_KV > p.S);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = s[kb][r] * sc;
-        if (tail) {
-          const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (key >= p.S) v = -1e30f;
-        }
-        pr[kb][r] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
-    m_run = m_new;
-    float ps = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = exp2f(pr[kb][r] - m_new);
-        pr[kb][r] = e;
-        ps += e;
-      }
-    l_run = l_run * alpha + ps;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-    pv_block(vt, 0, lane, pr[0], o);
-    pv_block(vt, 32, lane, pr[1], o);
+    if (t < nfull) fa_tile<false>(kt, vt, qf, lane, t * FA_KV, p.S, sc, m_run, l_run, o);
+    else fa_tile<true>(kt, vt, qf, lane, t * FA_KV, p.S, sc, m_run, l_run, o);
     buf ^= 1;
   }
   l_run += __shfl_xor(l_run, 32);
