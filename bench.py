@@ -151,6 +151,13 @@ def main():
                                "kernel": "gemm_kernel<BN,CONV,UNI> (all linear / 3x3 / 1x1 / temporal-conv / attention GEMM launches)",
                                "launches": g_calls, "avg_launch_us": round(g_ms * 1000.0 / max(g_calls, 1), 2),
                                "algorithmic_tflop": round(g_fl / 1e12, 2)}
+            try:   # HBM traffic of the same kernel family from the committed PMC passes (tools/pmc_traffic.sh)
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_gemm.json")))
+                res["roofline"]["traffic"] = round(pm["hbm_bytes_per_launch"])
+                res["roofline"]["traffic_note"] = ("bytes per gemm_kernel launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes "
+                                                   "on a 3-step clip (profiles/r01_pmc_traffic_gemm.json), FETCH doubled per the gfx950 note")
+            except Exception:
+                pass
             res["kernel_ms"] = {k: round(v["ms"], 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
             if full:
                 clip_tflop = a.denoise_steps * TFLOP_UNET + TFLOP_VAE_ENC + TFLOP_VAE_DEC + TFLOP_CLIP

@@ -549,11 +549,12 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
   const int nk = cdiv(p.K, 64);
   const bool plain_epi = !geglu && !(p.flags & UG_F_OUT_F32) && batch == 1 && (p.N % 8 == 0) && (p.ldo % 8 == 0) &&
                          (!p.R1 || p.ldr1 % 8 == 0) && (!p.R2 || p.ldr2 % 8 == 0);
-  if (plain_epi && tiles128 <= 128 && nk >= 16 && p.N >= 128) {   // under half a wave of workgroups and a long K loop
+  if (plain_epi && tiles128 <= 128 && nk >= 64 && p.N >= 128) {   // under half a wave of workgroups and a long K loop
     split = (int)std::min<long>(8, std::max<long>(1, 768 / tiles128));
-    split = std::min(split, nk / 4);
+    split = std::min(split, nk / 16);
     if (split < 2) split = 1; else cfg = 0;
   }
+  if (split == 1 && !geglu && p.M <= 2048 && p.N < 2048) cfg = 12;   // lowest-resolution level: 64x64 tiles fill more CUs
   if (g_force_cfg >= 0) cfg = g_force_cfg;
   if (g_force_split >= 0) split = plain_epi ? std::max(1, g_force_split) : 1;
   *cfg_out = cfg; *split_out = split;
