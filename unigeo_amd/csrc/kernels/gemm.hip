@@ -517,6 +517,9 @@ static void launch_cfg(int cfg, const GemmP& p, int batch, hipStream_t s) {
     case 14: launch_mode<256, 64, 64, 2, 4, 2>(p, batch, s); break;   //  80 KiB, 8 waves
     case 15: launch_mode<256, 256, 64, 2, 2, 4>(p, batch, s); break;  // 128 KiB, 8 waves, wave tile 128x64
     case 16: launch_mode<256, 256, 64, 2, 4, 2>(p, batch, s); break;  // 128 KiB, 8 waves, wave tile 64x128
+    case 17: launch_mode<256, 256, 32, 4, 2, 4>(p, batch, s); break;  // 128 KiB, 3 tiles in flight
+    case 18: launch_mode<256, 256, 32, 3, 2, 4>(p, batch, s); break;  //  96 KiB, 2 tiles in flight
+    case 19: launch_mode<256, 128, 64, 3, 2, 4>(p, batch, s); break;  // 144 KiB, wave tile 128x32
     default: UG_REQUIRE(false, "unknown GEMM tile config");
   }
 }
@@ -541,7 +544,7 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
   if (geglu) cfg = 15;
   else if (p.conv)
     cfg = ((p.M >= 90000 && p.N % 256 == 0) || (p.M >= 16384 && p.N >= 512)) ? 15
-          : (p.M >= 90000 && p.N % 128 == 0) ? 0 : (p.M >= 50000 ? 14 : 1);
+          : (p.M >= 90000 && p.N == 128) ? 19 : (p.M >= 90000 && p.N % 128 == 0) ? 0 : (p.M >= 50000 ? 14 : 1);
   else
     cfg = (p.N >= 2048 || (p.M >= 16384 && p.N >= 512 && p.K >= 2048)) ? 15 : (p.M >= 50000 ? 14 : 1);
   int split = 1;
@@ -579,7 +582,7 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
   }
   int cfg = p.cfg_p1 - 1, split = p.splitk;
   if (cfg < 0 || split < 1) { int c2, s2; gemm_plan(p, batch, &c2, &s2); if (cfg < 0) cfg = c2; if (split < 1) split = s2; }
-  if (p.flags & UG_F_GEGLU) UG_REQUIRE(cfg == 0 || cfg == 2 || cfg == 4 || cfg == 5 || cfg == 7 || cfg == 8 || cfg == 9 || cfg == 13 || cfg == 15, "GEGLU needs a 64-column wave tile");
+  if (p.flags & UG_F_GEGLU) UG_REQUIRE(cfg == 0 || cfg == 2 || cfg == 4 || cfg == 5 || cfg == 7 || cfg == 8 || cfg == 9 || cfg == 13 || cfg == 15 || cfg == 17 || cfg == 18, "GEGLU needs a 64-column wave tile");
   p.splitk = split;
   if (split > 1) UG_REQUIRE(p.partial != nullptr, "split-K needs a partial buffer");
   launch_cfg(cfg, p, batch, s);

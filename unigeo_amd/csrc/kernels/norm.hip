@@ -224,6 +224,62 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply(const GroupNormP p, int r
 
 // rows per chunk: enough workgroups (T * nchunk >= ~1024) to fill 256 CUs several times over, but at
 // least 4 row-iterations per thread so the unrolled loads stay in flight; at most 128 chunks per frame.
+// ------------------------------------------------------------------------------------------
+// Small tensors (the low-resolution UNet levels): ONE launch.  A workgroup owns one group of one frame
+// (or of all frames for the temporal variant): pass 1 accumulates sum / sum-of-squares over its slab
+// (fixed-order tree => deterministic), pass 2 re-reads the slab (L2 resident) and applies.
+// 8-byte vectors: needs channels-per-group % 4 == 0 and C0 % 4 == 0.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_small(const GroupNormP p) {
+  __shared__ float rs[256], rq[256];
+  __shared__ float mr[2];
+  const int C = p.C0 + p.C1, cpg = C / p.G, vpg = cpg / 4;
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const long row0 = p.temporal ? 0 : (long)blockIdx.y * p.HW;
+  const long rows = p.temporal ? (long)p.T * p.HW : p.HW;
+  const long nitem = rows * vpg;
+  auto ld = [&](long m, int c) -> f16x4 {
+    return (c < p.C0) ? *(const f16x4*)(p.X0 + m * p.C0 + c) : *(const f16x4*)(p.X1 + m * p.C1 + (c - p.C0));
+  };
+  float s = 0.f, q = 0.f;
+  for (long it = tid; it < nitem; it += 256) {
+    const long r = it / vpg; const int v = (int)(it - r * vpg);
+    const f16x4 x = ld(row0 + r, g * cpg + v * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float f = (float)x[e]; s += f; q += f * f; }
+  }
+  rs[tid] = s; rq[tid] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) { rs[tid] += rs[tid + o]; rq[tid] += rq[tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double n = (double)rows * cpg;
+    const double mean = (double)rs[0] / n;
+    double var = (double)rq[0] / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mr[0] = (float)mean; mr[1] = (float)(1.0 / sqrt(var + (double)p.eps));
+  }
+  __syncthreads();
+  const float mean = mr[0], rstd = mr[1];
+  for (long it = tid; it < nitem; it += 256) {
+    const long r = it / vpg; const int v = (int)(it - r * vpg);
+    const int c = g * cpg + v * 4;
+    const f16x4 x = ld(row0 + r, c);
+    const f16x4 ga = *(const f16x4*)(p.gamma + c), be = *(const f16x4*)(p.beta + c);
+    f16x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = rstd * (float)ga[e];
+      float f = (float)x[e] * a + ((float)be[e] - mean * a);
+      if (p.silu) f = silu_f(f);
+      y[e] = (f16)f;
+    }
+    *(f16x4*)(p.Y + (row0 + r) * C + c) = y;
+  }
+}
+
 static inline void gn_chunks2(int T, int HW, int C, int& nchunk, int& rpc) {
   const GnGeom gg = gn_geom(C);
   const int want = cdiv(1024, T);                       // chunks per frame we would like
@@ -245,6 +301,15 @@ void launch_groupnorm(const GroupNormP& p, hipStream_t s) {
   UG_REQUIRE(p.C0 % 8 == 0 && p.C1 % 8 == 0, "GroupNorm channels must be multiples of 8");
   UG_REQUIRE(C % p.G == 0 && p.G <= 256 && 256 % p.G == 0, "GroupNorm group count must divide 256");
   UG_REQUIRE(C <= GN_MAXV * GN_THREADS * 8, "GroupNorm too many channels");
+  {
+    const int cpg = C / p.G;
+    const long slab = (long)p.HW * cpg * (p.temporal ? p.T : 1);
+    if (!p.temporal && cpg % 4 == 0 && p.C0 % 4 == 0 && p.gamma && p.beta && slab <= 16384) {
+      hipLaunchKernelGGL(gn_small, dim3(p.G, p.temporal ? 1 : p.T), dim3(256), 0, s, p);
+      UG_CHECK(hipGetLastError());
+      return;
+    }
+  }
   int nchunk, rpc;
   gn_chunks2(p.T, p.HW, C, nchunk, rpc);
   const GnGeom gg = gn_geom(C);
