@@ -1,0 +1,21 @@
+#!/usr/bin/env python
+"""python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/eval_sharded.py CONFIG.yaml
+One process per GPU; clips sharded over ranks; rank 0 writes debug_output/metrics.csv."""
+import os, sys
+import yaml
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.distributed as dist
+from unigeo_amd.harness import SyntheticGeometryDataset, parse_dataset_config, import_class_from_module
+from unigeo_amd.harness.distributed import evaluate_sharded
+
+cfg = yaml.safe_load(open(sys.argv[1]))
+world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+if world > 1:
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl")
+ds = import_class_from_module("unigeo_amd.harness.dataset", cfg["dataset"])(**parse_dataset_config(cfg))
+model = import_class_from_module("unigeo_amd.model", cfg["model_name"])(device_id=local, **cfg["model_params"])
+rows, mm = evaluate_sharded(cfg, ds, model, dist=dist if world > 1 else None, verbose=(local == 0))
+if world > 1:
+    dist.destroy_process_group()

@@ -106,7 +106,7 @@ struct FlashP {
 void launch_flash_attn64(const FlashP& p, hipStream_t s);
 
 // Temporal self-attention: for every pixel p and head h, sequence over the T frames
-// (row of frame t = t*HW + p), head_dim 64, T <= 64.
+// (row of frame t = t*HW + p), head_dim 64, T <= 64 (BASELINE config 5 uses 50-frame clips).
 struct TemporalAttnP {
   const f16* Q; const f16* K; const f16* V; long ld;
   f16* O; long ldo;

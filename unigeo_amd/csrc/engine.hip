@@ -923,7 +923,7 @@ f16* clip_embed(Ctx& c, const f16* video_m11, int T, int H, int W) {
 void dc_set_inputs(Ctx& c, const float* frames, int T, int H, int W, const float* noise_lat, const float* noise_aug,
                    const float* K33) {
   UG_REQUIRE(H % 64 == 0 && W % 64 == 0, "height and width must be multiples of 64 (VAE /8, UNet /8)");
-  UG_REQUIRE(T >= 1 && T <= 32, "1..32 frames per clip");
+  UG_REQUIRE(T >= 1 && T <= 64, "1..64 frames per clip");
   if (c.io_ready) { c.ws.release(c.io_mark); c.io_ready = false; }
   c.io_mark = c.ws.mark();
   c.T = T; c.H = H; c.W = W;

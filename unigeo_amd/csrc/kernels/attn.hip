@@ -204,8 +204,11 @@ void launch_flash_attn64(const FlashP& p, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 // temporal attention: sequence = the T frames of one pixel; one wave per (pixel, head).
 // ------------------------------------------------------------------------------------------
+// NB = number of 32-frame blocks (1: T <= 32, 2: T <= 64).  Each wave handles one (pixel, head): all NB*32 key rows'
+// V slab sits in its private LDS region, every 32-query block sees all keys at once (plain softmax, no rescaling).
+template <int NB>
 __global__ __launch_bounds__(256) void temporal_attn64_kernel(const TemporalAttnP p) {
-  __shared__ __attribute__((aligned(16))) f16 lds[4 * 32 * 64];  // one 32x64 V slab per wave
+  __shared__ __attribute__((aligned(16))) f16 lds[4 * NB * 32 * 64];  // one (NB*32)x64 V slab per wave
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long pix = (long)blockIdx.x * 4 + wave;
@@ -213,75 +216,94 @@ __global__ __launch_bounds__(256) void temporal_attn64_kernel(const TemporalAttn
   if (pix >= p.HW) return;   // wave-uniform; no block-level barrier is used below
   const int qi = lane & 31, hh = lane >> 5;
   const float sc = p.scale * 1.4426950408889634f;
-  f16* vt = lds + wave * (32 * 64);
-  const bool ok = qi < p.T;
-  const long rowq = (long)(ok ? qi : 0) * p.HW + pix;
-
-  // V slab: 32 rows x 128 B = 4 wave-instructions of 8 rows
+  f16* vt = lds + wave * (NB * 32 * 64);
   {
     const int pc = lane & 7;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 4 * NB; ++j) {   // wave-instructions of 8 rows x 128 B
       const int r = j * 8 + (lane >> 3);
       const int rr = r < p.T ? r : 0;   // padded keys get P == 0
       const f16* vs = p.V + ((long)rr * p.HW + pix) * p.ld + h * 64 + ((pc ^ vswz(r)) * 8);
       __builtin_amdgcn_global_load_lds((gptr_t)vs, (lptr_t)(vt + j * 8 * 64), 16, 0, 0);
     }
   }
-  f16x8 qf[4], kf[4];
+  f16x8 kf[NB][4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    qf[c] = *(const f16x8*)(p.Q + rowq * p.ld + h * 64 + c * 16 + hh * 8);
-    kf[c] = *(const f16x8*)(p.K + rowq * p.ld + h * 64 + c * 16 + hh * 8);
+  for (int kb = 0; kb < NB; ++kb) {
+    const int t = kb * 32 + qi;
+    const long row = (long)(t < p.T ? t : 0) * p.HW + pix;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) kf[kb][c] = *(const f16x8*)(p.K + row * p.ld + h * 64 + c * 16 + hh * 8);
   }
-  f32x16 s;
+  bool waited = false;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) s[r] = 0.f;
+  for (int qb = 0; qb < NB; ++qb) {
+    const int tq = qb * 32 + qi;
+    if (qb * 32 >= p.T) break;        // wave-uniform
+    const bool ok = tq < p.T;
+    const long rowq = (long)(ok ? tq : 0) * p.HW + pix;
+    f16x8 qf[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[c], qf[c], s, 0, 0, 0);
-  float pr[16];
-  float mx = -1e30f;
+    for (int c = 0; c < 4; ++c) qf[c] = *(const f16x8*)(p.Q + rowq * p.ld + h * 64 + c * 16 + hh * 8);
+    float pr[NB][16];
+    float mx = -1e30f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int key = (r & 3) + 8 * (r >> 2) + 4 * hh;
-    float v = s[r] * sc;
-    if (key >= p.T) v = -1e30f;
-    pr[r] = v;
-    mx = fmaxf(mx, v);
-  }
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
-  float ps = 0.f;
+    for (int kb = 0; kb < NB; ++kb) {
+      f32x16 s;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { pr[r] = exp2f(pr[r] - mx); ps += pr[r]; }
-  ps += __shfl_xor(ps, 32);
-  f32x16 o[2];
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+      for (int c = 0; c < 4; ++c) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][c], qf[c], s, 0, 0, 0);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-  pv_block(vt, 0, lane, pr, o);
-  if (ok) {
-    const float inv = 1.0f / ps;
-    f16* dst = p.O + rowq * p.ldo + h * 64;
+      for (int r = 0; r < 16; ++r) {
+        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        float v = s[r] * sc;
+        if (key >= p.T) v = -1e30f;
+        pr[kb][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float ps = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { pr[kb][r] = __builtin_amdgcn_exp2f(pr[kb][r] - mx); ps += pr[kb][r]; }
+    ps += __shfl_xor(ps, 32);
+    f32x16 o[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        f16x4 v;
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    if (!waited) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      waited = true;
+    }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (f16)(o[dt][r4 * 4 + e] * inv);
-        *(f16x4*)(dst + dt * 32 + 8 * r4 + 4 * hh) = v;
-      }
+    for (int kb = 0; kb < NB; ++kb) pv_block(vt, kb * 32, lane, pr[kb], o);
+    if (ok) {
+      const float inv = 1.0f / ps;
+      f16* dst = p.O + rowq * p.ldo + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          f16x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (f16)(o[dt][r4 * 4 + e] * inv);
+          *(f16x4*)(dst + dt * 32 + 8 * r4 + 4 * hh) = v;
+        }
+    }
   }
 }
 
 void launch_temporal_attn64(const TemporalAttnP& p, hipStream_t s) {
-  UG_REQUIRE(p.T >= 1 && p.T <= 32, "temporal attention supports up to 32 frames per clip");
+  UG_REQUIRE(p.T >= 1 && p.T <= 64, "temporal attention supports up to 64 frames per clip");
   UG_REQUIRE(p.ld % 8 == 0 && p.ldo % 4 == 0, "temporal attention strides");
   dim3 grid(cdiv(p.HW, 4), p.H);
-  hipLaunchKernelGGL(temporal_attn64_kernel, grid, dim3(256), 0, s, p);
+  if (p.T <= 32) hipLaunchKernelGGL(temporal_attn64_kernel<1>, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(temporal_attn64_kernel<2>, grid, dim3(256), 0, s, p);
   UG_CHECK(hipGetLastError());
 }
 

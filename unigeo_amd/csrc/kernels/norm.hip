@@ -105,13 +105,13 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats(const GroupNormP p, int n
   }
 }
 
-__global__ __launch_bounds__(256) void gn_finalize(const GroupNormP p, int nchunk, float* ab) {
-  // grid (T), 256 threads: 256/G threads cooperate on one group's chunk partials (fp64, fixed order)
-  __shared__ double sa[256], sb[256];
+__global__ __launch_bounds__(1024) void gn_finalize(const GroupNormP p, int nchunk, float* ab) {
+  // grid (T), NT = 256 or 1024 threads: NT/G threads cooperate on one group's chunk partials (fp64, fixed order)
+  __shared__ double sa[1024], sb[1024];
   __shared__ float mr[2 * 256];
   const int C = p.C0 + p.C1, cpg = C / p.G, G = p.G;
-  const int t = blockIdx.x, tid = threadIdx.x;
-  const int SUB = 256 / G;
+  const int t = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+  const int SUB = NT / G;
   const int g = tid % G, sub = tid / G;
   const int tlo = p.temporal ? 0 : t, thi = p.temporal ? p.T : t + 1;
   const int nitem = (thi - tlo) * nchunk;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void gn_finalize(const GroupNormP p, int nchun
     mr[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
+  for (int c = tid; c < C; c += NT) {
     const int gg = c / cpg;
     const float ga = p.gamma ? (float)p.gamma[c] : 1.f, be = p.beta ? (float)p.beta[c] : 0.f;
     const float sc = mr[2 * gg + 1] * ga;
@@ -316,7 +316,8 @@ void launch_groupnorm(const GroupNormP& p, hipStream_t s) {
   float* ab = p.ws + (size_t)p.T * nchunk * p.G * 2;
   const size_t lds = (size_t)gg.rpi * C * 2 * sizeof(float);
   hipLaunchKernelGGL(gn_stats, dim3(nchunk, p.T), dim3(GN_THREADS), lds, s, p, nchunk, rpc);
-  hipLaunchKernelGGL(gn_finalize, dim3(p.T), dim3(256), 0, s, p, nchunk, ab);
+  const int fin_threads = ((p.temporal ? p.T : 1) * nchunk > 64) ? 1024 : 256;
+  hipLaunchKernelGGL(gn_finalize, dim3(p.T), dim3(fin_threads), 0, s, p, nchunk, ab);
   hipLaunchKernelGGL(gn_apply, dim3(nchunk, p.T), dim3(GN_THREADS), 0, s, p, rpc, (const float*)ab);
   UG_CHECK(hipGetLastError());
 }
