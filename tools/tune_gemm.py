@@ -9,7 +9,7 @@ if os.environ.get('UG_KNOBS'):
     eng.lib.ug_tune_force(-100 - int(os.environ['UG_KNOBS']), 0)
 CFG = {0: "128x128x64s2", 1: "128x64x64s2", 2: "128x128x64s3", 3: "128x64x64s3", 4: "256x128x64s3", 5: "128x128x32s4",
        6: "256x256x32s3", 7: "256x128x32s4", 8: "256x128x64s2", 9: "128x128x32s3",
-       10: "128x64x32s2", 11: "128x64x32s4", 12: "64x64x64s2", 13: "64x128x64s2", 14: "256x64x64s2", 15: "256x256x64s2(2x4)", 16: "256x256x64s2(4x2)", 17: "256x256x32s4", 18: "256x256x32s3", 19: "256x128x64s3(2x4)"}
+       10: "128x64x32s2", 11: "128x64x32s4", 12: "64x64x64s2", 13: "64x128x64s2", 14: "256x64x64s2", 15: "256x256x64s2(2x4)", 16: "256x256x64s2(4x2)", 17: "256x256x32s4", 18: "256x256x32s3", 19: "256x128x64s3(2x4)", 20: "256x128x32s2(4w)", 21: "128x256x32s2(4w)", 22: "256x128x32s3(4w)"}
 dense = [(76800, 2560, 320), (76800, 320, 1280), (76800, 320, 320), (76800, 960, 320), (19200, 5120, 640),
          (19200, 640, 2560), (19200, 640, 640), (4800, 10240, 1280), (4800, 1280, 5120), (4800, 1280, 1280),
          (1200, 10240, 1280), (1200, 1280, 5120), (6425, 5120, 1280), (8192, 8192, 8192)]

@@ -118,8 +118,10 @@ __device__ __forceinline__ void fa_tile(const f16* kt, const f16* vt, const f16x
   pv_block(vt, 32, lane, pr[1], o);
 }
 
+#define FA_NST 3   // KV ring depth: a 64-key tile is ~0.4 us of math, far less than the load latency -> keep 3 tiles in flight
+
 __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const FlashP p) {
-  __shared__ __attribute__((aligned(16))) f16 lds[2 * 2 * FA_KV * 64];  // [buf][K|V][64][64]
+  __shared__ __attribute__((aligned(16))) f16 lds[FA_NST * 2 * FA_KV * 64];  // [slot][K|V][64][64]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.z, h = blockIdx.y;
@@ -165,17 +167,25 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const FlashP p) {
 
   const int ntile = (p.S + FA_KV - 1) / FA_KV;
   const int nfull = p.S / FA_KV;
-  stage(0, 0);
-  int buf = 0;
+#pragma unroll
+  for (int s0 = 0; s0 < FA_NST - 1; ++s0)
+    if (s0 < ntile) stage(s0 * FA_KV, s0);
+  int buf = 0, ld = FA_NST - 1;   // ring slots of the tile being consumed / the next tile to fetch
   for (int t = 0; t < ntile; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < ntile) stage((t + 1) * FA_KV, buf ^ 1);
+    // each thread issued 4 loads per tile; up to FA_NST-2 younger tiles may stay in flight
+    const int younger = min(FA_NST - 2, ntile - 1 - t);
+    if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // raw barrier: does not drain the LDS-DMA queue
+    asm volatile("" ::: "memory");
+    if (t + FA_NST - 1 < ntile) { stage((t + FA_NST - 1) * FA_KV, ld); }
+    if (++ld == FA_NST) ld = 0;
     const f16* kt = lds + buf * (2 * FA_KV * 64);
     const f16* vt = kt + FA_KV * 64;
     if (t < nfull) fa_tile<false>(kt, vt, qf, lane, t * FA_KV, p.S, sc, m_run, l_run, o);
     else fa_tile<true>(kt, vt, qf, lane, t * FA_KV, p.S, sc, m_run, l_run, o);
-    buf ^= 1;
+    if (++buf == FA_NST) buf = 0;
   }
   l_run += __shfl_xor(l_run, 32);
   const float inv = 1.0f / l_run;

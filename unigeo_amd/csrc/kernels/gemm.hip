@@ -520,6 +520,9 @@ static void launch_cfg(int cfg, const GemmP& p, int batch, hipStream_t s) {
     case 17: launch_mode<256, 256, 32, 4, 2, 4>(p, batch, s); break;  // 128 KiB, 3 tiles in flight
     case 18: launch_mode<256, 256, 32, 3, 2, 4>(p, batch, s); break;  //  96 KiB, 2 tiles in flight
     case 19: launch_mode<256, 128, 64, 3, 2, 4>(p, batch, s); break;  // 144 KiB, wave tile 128x32
+    case 20: launch_mode<256, 128, 32, 2, 2, 2>(p, batch, s); break;  //  48 KiB, 4 waves, wave tile 128x64
+    case 21: launch_mode<128, 256, 32, 2, 2, 2>(p, batch, s); break;  //  48 KiB, 4 waves, wave tile 64x128
+    case 22: launch_mode<256, 128, 32, 3, 2, 2>(p, batch, s); break;  //  72 KiB, 4 waves, wave tile 128x64
     default: UG_REQUIRE(false, "unknown GEMM tile config");
   }
 }
