@@ -24,7 +24,7 @@ convs = [("vae128@384x512", 128, dict(T=8, H=384, W=512, C0=128, C1=0, kt=1, k=3
          ("tconv320@48x64", 320, dict(T=25, H=48, W=64, C0=320, C1=0, kt=3, k=1)),
          ("tconv1280@6x8", 1280, dict(T=25, H=6, W=8, C0=1280, C1=0, kt=3, k=1)),
          ("tconv128@384x512", 128, dict(T=8, H=384, W=512, C0=128, C1=0, kt=3, k=1))]
-cfgs = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]
+cfgs = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 3, 4, 8, 12, 14, 15, 19]
 splits = [1, 2, 4, 8]
 print(CFG)
 print("dense")

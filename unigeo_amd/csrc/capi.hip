@@ -1,4 +1,5 @@
 // extern "C" surface of libunigeo_hip.so (declared in include/unigeo_hip.h).
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -387,12 +388,22 @@ int ug_bench_gemm(ug_ctx* x, int M, int N, int K, int conv, int T, int Hi, int W
       p.C0 = C0; p.C1 = C1; M = T * p.Ho * p.Wo; K = (C0 + C1) * kt * k * k;
       asz = (long)T * Hi * Wi * C0;
     } else { p.C0 = K; asz = (long)M * K; }
-    f16* A = c.ws.get<f16>(asz); f16* A1 = C1 ? c.ws.get<f16>((long)T * Hi * Wi * C1) : nullptr;
-    f16* Wt = c.ws.get<f16>((long)N * K); f16* O = c.ws.get<f16>((long)M * N); f16* b = c.ws.get<f16>(N);
-    launch_fill_random(A, asz, 1, c.stream); if (A1) launch_fill_random(A1, (long)T * Hi * Wi * C1, 2, c.stream);
+    // rotate through enough distinct A / output buffers to exceed the 256 MiB Infinity Cache: in the pipeline the
+    // activation operand was just streamed out by the previous kernel and does not sit in cache
+    const long a1sz = C1 ? (long)T * Hi * Wi * C1 : 0;
+    const long per = (asz + a1sz + (long)M * N) * 2;
+    int nbuf = (int)std::min<long>(16, std::max<long>(2, (600L << 20) / std::max<long>(per, 1) + 1));
+    if (getenv("UG_BENCH_WARM")) nbuf = 1;
+    std::vector<f16*> As(nbuf), A1s(nbuf), Os(nbuf);
+    for (int i = 0; i < nbuf; ++i) {
+      As[i] = c.ws.get<f16>(asz); A1s[i] = C1 ? c.ws.get<f16>(a1sz) : nullptr; Os[i] = c.ws.get<f16>((long)M * N);
+      launch_fill_random(As[i], asz, 1 + i, c.stream); if (C1) launch_fill_random(A1s[i], a1sz, 100 + i, c.stream);
+    }
+    f16* Wt = c.ws.get<f16>((long)N * K); f16* b = c.ws.get<f16>(N);
     launch_fill_random(Wt, (long)N * K, 3, c.stream); launch_fill_random(b, N, 4, c.stream);
-    p.A0 = A; p.A1 = A1; p.M = M; p.N = N; p.K = K; p.W = Wt; p.ldw = K; p.bias = b; p.c0 = 1.f; p.Out = O; p.ldo = N;
+    p.M = M; p.N = N; p.K = K; p.W = Wt; p.ldw = K; p.bias = b; p.c0 = 1.f; p.ldo = N;
     p.zero = c.zero; p.nb_inner = 1;
+    p.A0 = As[0]; p.A1 = A1s[0]; p.Out = Os[0];
     int cf = cfg, sp = split;
     if (cf < 0 || sp < 1) { int c2, s2; gemm_plan(p, 1, &c2, &s2); if (cf < 0) cf = c2; if (sp < 1) sp = s2; }
     p.cfg_p1 = cf + 1; p.splitk = sp;
@@ -400,7 +411,7 @@ int ug_bench_gemm(ug_ctx* x, int M, int N, int K, int conv, int T, int Hi, int W
     for (int i = 0; i < 2; ++i) launch_gemm(p, 1, c.stream);
     hipEvent_t e0, e1; UG_CHECK(hipEventCreate(&e0)); UG_CHECK(hipEventCreate(&e1));
     UG_CHECK(hipEventRecord(e0, c.stream));
-    for (int i = 0; i < iters; ++i) launch_gemm(p, 1, c.stream);
+    for (int i = 0; i < iters; ++i) { p.A0 = As[i % nbuf]; p.A1 = A1s[i % nbuf]; p.Out = Os[i % nbuf]; launch_gemm(p, 1, c.stream); }
     UG_CHECK(hipEventRecord(e1, c.stream)); UG_CHECK(hipEventSynchronize(e1));
     float ms; UG_CHECK(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

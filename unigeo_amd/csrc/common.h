@@ -64,6 +64,7 @@ struct GemmP {
   int cfg_p1;            // 0 = pick the tile config automatically, else tile config id + 1
   int splitk;            // 0 = automatic, 1 = off, >1 = K slices (needs `partial`)
   float* partial;        // split-K scratch: splitk * M * N floats
+  int up_phase;          // 0 = off; 1 + (a*2+b): conv output row (t,y,x) is stored at row (t, 2y+a, 2x+b) of a 2Ho x 2Wo grid
 };
 void launch_gemm(const GemmP& p, int batch, hipStream_t s);
 void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out);   // heuristic used when cfg/splitk are 0
@@ -130,6 +131,7 @@ void launch_cast_f16_f32(const f16* in, float* out, long n, hipStream_t s);
 // weight re-layouts (one-off at bind time)
 void launch_permute_conv_w(const f16* in, f16* out, int O, int I, int taps, int Ipad, int Opad,
                            hipStream_t s);   // [O][I][taps] -> [Opad][taps][Ipad] (zero padded)
+void launch_upsample_phase_w(const f16* w9, f16* w4, int O, int I, int Ipad, hipStream_t s);   // [O][I][3][3] -> 4 x [O][2*2][Ipad]
 void launch_gather_rows(const f16* in, f16* out, const int* rowmap, int rows, int cols, hipStream_t s);
 void launch_copy2d(const f16* in, long ldi, f16* out, long ldo, long rows, int cols, hipStream_t s);
 void launch_fill_f16(f16* p, float v, long n, hipStream_t s);

@@ -29,7 +29,8 @@ class Arena {
 };
 
 struct Lin { const f16* w = nullptr; const f16* b = nullptr; int in = 0, out = 0; };
-struct Conv { const f16* w = nullptr; const f16* b = nullptr; int cin = 0, cinp = 0, cout = 0, kt = 1, ky = 1, kx = 1; };
+struct Conv { const f16* w = nullptr; const f16* b = nullptr; int cin = 0, cinp = 0, cout = 0, kt = 1, ky = 1, kx = 1;
+              const f16* wphase = nullptr; };   // wphase: 4 x [cout][2*2][cinp] sub-pixel weights of a nearest-2x upsample conv
 struct Norm { const f16* g = nullptr; const f16* b = nullptr; int c = 0; float eps = 1e-5f; };
 
 struct Res2D { Norm n1, n2; Conv c1, c2, sc; Lin temb; bool has_sc = false, has_temb = false; int tidx = -1; };

@@ -3,6 +3,7 @@
 #include "engine.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -83,7 +84,8 @@ static void run_gemm(Ctx& c, GemmP p, int batch, const char* tag) {
   const size_t mk = c.ws.mark();
   if (split > 1) p.partial = c.ws.get<float>((long)split * p.M * p.N);
   {
-    ProfScope ps(c, nm, 2.0 * p.M * p.N * (double)p.K * batch, 0);
+    // algorithmic FLOPs: a sub-pixel phase of an upsample conv stands for 9/4 of the MACs it executes
+    ProfScope ps(c, nm, 2.0 * p.M * p.N * (double)p.K * batch * (p.up_phase ? 2.25 : 1.0), 0);
     launch_gemm(p, batch, c.stream);
   }
   c.ws.release(mk);
@@ -108,6 +110,21 @@ static void linear(Ctx& c, const f16* A, long M, const Lin& l, f16* out, const E
 static void conv(Ctx& c, const f16* x0, int C0, const f16* x1, int C1, int T, int Hi, int Wi, const Conv& cv,
                  int stride, int pad_t, int pad_l, int ups, f16* out, const Epi& e = Epi(), long ldo = 0) {
   UG_REQUIRE(C0 + C1 == cv.cinp, "conv input channels do not match the bound weight");
+  if (ups == 2 && cv.wphase && stride == 1 && pad_t == 1 && pad_l == 1) {
+    // sub-pixel decomposition: four 2x2 convs on the source grid (4*Cin instead of 9*Cin MACs per output)
+    for (int ph = 0; ph < 4; ++ph) {
+      GemmP p; memset(&p, 0, sizeof(p));
+      p.conv = 1; p.A0 = x0; p.A1 = x1; p.C0 = C0; p.C1 = C1;
+      p.T = T; p.Hi = Hi; p.Wi = Wi; p.ups = 1; p.stride = 1; p.pad_t = (ph >> 1) ? 0 : 1; p.pad_l = (ph & 1) ? 0 : 1;
+      p.kt = 1; p.ky = 2; p.kx = 2; p.Ho = Hi; p.Wo = Wi;
+      p.M = T * Hi * Wi; p.N = cv.cout; p.K = cv.cinp * 4;
+      p.W = cv.wphase + (long)ph * cv.cout * 4 * cv.cinp; p.ldw = p.K; p.bias = cv.b; p.bias2 = e.bias2;
+      p.c0 = e.c0; p.act = e.act; p.flags = e.flags; p.Out = out; p.ldo = ldo ? ldo : cv.cout; p.up_phase = 1 + ph;
+      UG_REQUIRE(!e.R1 && !e.R2, "sub-pixel upsample conv does not take residuals");
+      run_gemm(c, p, 1, "gemm_conv_up2x2");
+    }
+    return;
+  }
   GemmP p; memset(&p, 0, sizeof(p));
   p.conv = 1; p.A0 = x0; p.A1 = x1; p.C0 = C0; p.C1 = C1;
   p.T = T; p.Hi = Hi; p.Wi = Wi; p.ups = ups; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
@@ -259,7 +276,7 @@ static Lin bind_geglu(Ctx& c, const std::string& p, int in, int inner) {
 }
 static inline int pad8(int x) { return (x + 7) & ~7; }
 // Conv2d [O][I][k][k] -> [O][k*k][Ipad];  Conv3d [O][I][3][1][1] -> [O][3][Ipad]
-static Conv bind_conv(Ctx& c, const std::string& p, int cin, int cout, int kt, int k, bool bias = true) {
+static Conv bind_conv(Ctx& c, const std::string& p, int cin, int cout, int kt, int k, bool bias = true, bool upsampler = false) {
   Conv cv; cv.cin = cin; cv.cinp = pad8(cin); cv.cout = cout; cv.kt = kt; cv.ky = k; cv.kx = k;
   RawTensor* t;
   if (kt > 1) t = &raw_get(c, p + ".weight", {cout, cin, kt, 1, 1});
@@ -271,6 +288,14 @@ static Conv bind_conv(Ctx& c, const std::string& p, int cin, int cout, int kt, i
   UG_CHECK(hipStreamSynchronize(c.stream));
   c.persist.release(mk);
   cv.w = w;
+  if (upsampler && kt == 1 && k == 3 && !getenv("UG_NO_SUBPIXEL")) {
+    f16* w4 = c.persist.get<f16>((long)4 * cout * 4 * cv.cinp);
+    const size_t mk2 = c.persist.mark();
+    launch_upsample_phase_w(raw_f16(c, *t, false), w4, cout, cin, cv.cinp, c.stream);
+    UG_CHECK(hipStreamSynchronize(c.stream));
+    c.persist.release(mk2);
+    cv.wphase = w4;
+  }
   cv.b = bias ? persist_f16(c, raw_get(c, p + ".bias", {cout})) : nullptr;
   return cv;
 }
@@ -388,7 +413,7 @@ void bind_unet(Ctx& c, const UNetCfg& cfg, const std::string& pre) {
         u.up[i].attn.push_back(bind_transformer(c, p + ".attentions." + std::to_string(j), out, cfg.heads[lev], cfg.cross_dim));
     }
     if (i != n - 1) {
-      u.up[i].up = bind_conv(c, pre + "up_blocks." + std::to_string(i) + ".upsamplers.0.conv", out, out, 1, 3);
+      u.up[i].up = bind_conv(c, pre + "up_blocks." + std::to_string(i) + ".upsamplers.0.conv", out, out, 1, 3, true, true);
       u.up[i].has_up = true;
     }
   }
@@ -447,7 +472,7 @@ void bind_vae(Ctx& c, const VAECfg& cfg, const std::string& pre) {
       v.dup[i].res.push_back(bind_stres(c, pre + "decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j),
                                         j == 0 ? prev : out, out, 0, 1e-6f, 1e-5f, true));
     if (i != n - 1) {
-      v.dup[i].up = bind_conv(c, pre + "decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", out, out, 1, 3);
+      v.dup[i].up = bind_conv(c, pre + "decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", out, out, 1, 3, true, true);
       v.dup[i].has_up = true;
     }
   }

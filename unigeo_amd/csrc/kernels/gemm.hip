@@ -358,6 +358,14 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int m = m0 + wm * WTM + i * 16 + l15;
+      long orow = m;
+      if (p.up_phase) {   // sub-pixel phase of a nearest-2x upsample conv: scatter to the (2y+a, 2x+b) output pixel
+        const int hw = p.Ho * p.Wo;
+        const int t = m / hw, rem = m - t * hw;
+        const int y = rem / p.Wo, x = rem - y * p.Wo;
+        const int ph = p.up_phase - 1;
+        orow = ((long)t * 2 * p.Ho + 2 * y + (ph >> 1)) * (2 * p.Wo) + 2 * x + (ph & 1);
+      }
       float v[WID];
 #pragma unroll
       for (int j = 0; j < NT; ++j)
@@ -396,14 +404,14 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
             for (int q = 0; q < 8; ++q) o[q] = gelu_f(o[q]);
           }
           if (of32) {
-            float* O = (float*)p.Out + out_off + (long)m * p.ldo + ob + e;
+            float* O = (float*)p.Out + out_off + orow * p.ldo + ob + e;
             *(f32x4*)O = (f32x4){o[0], o[1], o[2], o[3]};
             *(f32x4*)(O + 4) = (f32x4){o[4], o[5], o[6], o[7]};
           } else {
             f16x8 h;
 #pragma unroll
             for (int q = 0; q < 8; ++q) h[q] = (f16)o[q];
-            *(f16x8*)((f16*)p.Out + out_off + (long)m * p.ldo + ob + e) = h;
+            *(f16x8*)((f16*)p.Out + out_off + orow * p.ldo + ob + e) = h;
           }
         }
       } else {
@@ -416,8 +424,8 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
             if (p.R2) o += p.c2 * (float)p.R2[(long)m * p.ldr2 + n];
             if (p.act == UG_ACT_SILU) o = silu_f(o);
             else if (p.act == UG_ACT_GELU) o = gelu_f(o);
-            if (of32) ((float*)p.Out)[out_off + (long)m * p.ldo + n] = o;
-            else ((f16*)p.Out)[out_off + (long)m * p.ldo + n] = (f16)o;
+            if (of32) ((float*)p.Out)[out_off + orow * p.ldo + n] = o;
+            else ((f16*)p.Out)[out_off + orow * p.ldo + n] = (f16)o;
           }
         }
       }
@@ -497,33 +505,21 @@ static void launch_mode(const GemmP& p, int batch, hipStream_t s) {
   }
 }
 
-// Tile configurations.  id -> (BM, BN, BK, stages, waves M x N, LDS)
+// Tile configurations.  id -> (BM, BN, BK, stages, waves M x N, LDS).  Ids are stable (tools/tune_gemm.py, profiles/);
+// the variants that lost everywhere in profiles/r01_gemm_tile_tuning.txt (BK=32 rings, 3-4 stage rings at lower
+// occupancy, 64x128 / 4-wave 128x64 wave tiles) were removed from the build.
 static void launch_cfg(int cfg, const GemmP& p, int batch, hipStream_t s) {
   switch (cfg) {
     case 0: launch_mode<128, 128, 64, 2, 2, 2>(p, batch, s); break;   //  64 KiB, 2 WG/CU
     case 1: launch_mode<128, 64, 64, 2, 2, 2>(p, batch, s); break;    //  48 KiB, 3 WG/CU
-    case 2: launch_mode<128, 128, 64, 3, 2, 2>(p, batch, s); break;   //  96 KiB, 1 WG/CU
     case 3: launch_mode<128, 64, 64, 3, 2, 2>(p, batch, s); break;    //  72 KiB, 2 WG/CU
     case 4: launch_mode<256, 128, 64, 3, 4, 2>(p, batch, s); break;   // 144 KiB, 1 WG/CU (8 waves)
-    case 5: launch_mode<128, 128, 32, 4, 2, 2>(p, batch, s); break;   //  64 KiB, 2 WG/CU
-    case 6: launch_mode<256, 256, 32, 3, 4, 2>(p, batch, s); break;   //  96 KiB, 1 WG/CU (8 waves)
-    case 7: launch_mode<256, 128, 32, 4, 4, 2>(p, batch, s); break;   //  96 KiB, 1 WG/CU (8 waves)
     case 8: launch_mode<256, 128, 64, 2, 4, 2>(p, batch, s); break;   //  96 KiB, 1 WG/CU (8 waves)
-    case 9: launch_mode<128, 128, 32, 3, 2, 2>(p, batch, s); break;   //  48 KiB, 3 WG/CU
-    case 10: launch_mode<128, 64, 32, 2, 2, 2>(p, batch, s); break;   //  24 KiB
-    case 11: launch_mode<128, 64, 32, 4, 2, 2>(p, batch, s); break;   //  48 KiB
-    case 12: launch_mode<64, 64, 64, 2, 2, 2>(p, batch, s); break;    //  32 KiB
-    case 13: launch_mode<64, 128, 64, 2, 2, 2>(p, batch, s); break;   //  48 KiB
-    case 14: launch_mode<256, 64, 64, 2, 4, 2>(p, batch, s); break;   //  80 KiB, 8 waves
+    case 12: launch_mode<64, 64, 64, 2, 2, 2>(p, batch, s); break;    //  32 KiB, 5 WG/CU
+    case 14: launch_mode<256, 64, 64, 2, 4, 2>(p, batch, s); break;   //  80 KiB, 2 WG/CU (8 waves)
     case 15: launch_mode<256, 256, 64, 2, 2, 4>(p, batch, s); break;  // 128 KiB, 8 waves, wave tile 128x64
-    case 16: launch_mode<256, 256, 64, 2, 4, 2>(p, batch, s); break;  // 128 KiB, 8 waves, wave tile 64x128
-    case 17: launch_mode<256, 256, 32, 4, 2, 4>(p, batch, s); break;  // 128 KiB, 3 tiles in flight
-    case 18: launch_mode<256, 256, 32, 3, 2, 4>(p, batch, s); break;  //  96 KiB, 2 tiles in flight
-    case 19: launch_mode<256, 128, 64, 3, 2, 4>(p, batch, s); break;  // 144 KiB, wave tile 128x32
-    case 20: launch_mode<256, 128, 32, 2, 2, 2>(p, batch, s); break;  //  48 KiB, 4 waves, wave tile 128x64
-    case 21: launch_mode<128, 256, 32, 2, 2, 2>(p, batch, s); break;  //  48 KiB, 4 waves, wave tile 64x128
-    case 22: launch_mode<256, 128, 32, 3, 2, 2>(p, batch, s); break;  //  72 KiB, 4 waves, wave tile 128x64
-    default: UG_REQUIRE(false, "unknown GEMM tile config");
+    case 19: launch_mode<256, 128, 64, 3, 2, 4>(p, batch, s); break;  // 144 KiB, 8 waves, wave tile 128x32
+    default: UG_REQUIRE(false, "unknown / pruned GEMM tile config");
   }
 }
 
@@ -553,7 +549,7 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
   int split = 1;
   const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * batch;
   const int nk = cdiv(p.K, 64);
-  const bool plain_epi = !geglu && !(p.flags & UG_F_OUT_F32) && batch == 1 && (p.N % 8 == 0) && (p.ldo % 8 == 0) &&
+  const bool plain_epi = !geglu && !p.up_phase && !(p.flags & UG_F_OUT_F32) && batch == 1 && (p.N % 8 == 0) && (p.ldo % 8 == 0) &&
                          (!p.R1 || p.ldr1 % 8 == 0) && (!p.R2 || p.ldr2 % 8 == 0);
   if (plain_epi && tiles128 <= 128 && nk >= 64 && p.N >= 128) {   // under half a wave of workgroups and a long K loop
     split = (int)std::min<long>(8, std::max<long>(1, 768 / tiles128));
@@ -585,7 +581,7 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
   }
   int cfg = p.cfg_p1 - 1, split = p.splitk;
   if (cfg < 0 || split < 1) { int c2, s2; gemm_plan(p, batch, &c2, &s2); if (cfg < 0) cfg = c2; if (split < 1) split = s2; }
-  if (p.flags & UG_F_GEGLU) UG_REQUIRE(cfg == 0 || cfg == 2 || cfg == 4 || cfg == 5 || cfg == 7 || cfg == 8 || cfg == 9 || cfg == 13 || cfg == 15 || cfg == 17 || cfg == 18, "GEGLU needs a 64-column wave tile");
+  if (p.flags & UG_F_GEGLU) UG_REQUIRE(cfg == 0 || cfg == 4 || cfg == 8 || cfg == 15, "GEGLU needs a 64-column wave tile");
   p.splitk = split;
   if (split > 1) UG_REQUIRE(p.partial != nullptr, "split-K needs a partial buffer");
   launch_cfg(cfg, p, batch, s);

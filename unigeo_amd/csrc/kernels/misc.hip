@@ -34,6 +34,32 @@ void launch_permute_conv_w(const f16* in, f16* out, int O, int I, int taps, int 
   hipLaunchKernelGGL(k_permute_conv_w, gs_grid((long)Opad * taps * Ipad), dim3(256), 0, s, in, out, O, I, taps, Ipad, Opad);
 }
 
+// nearest-2x upsample followed by a zero-padded 3x3 conv == four 2x2 convs on the source grid, one per output parity
+// (a,b): rows 2y-1,2y,2y+1 of the upsampled image are source rows y-1,y,y (a=0) or y,y,y+1 (a=1), so the 3 taps
+// collapse to 2 with weights {w0, w1+w2} or {w0+w1, w2}; same along x.  Sums are formed in fp32 and rounded once.
+__global__ void k_upsample_phase_w(const f16* w9, f16* w4, int O, int I, int Ipad) {
+  const long n = (long)4 * O * 4 * Ipad;
+  GS_LOOP(idx, n) {
+    const int i = idx % Ipad;
+    const int tap = (idx / Ipad) % 4;
+    const int o = (idx / ((long)Ipad * 4)) % O;
+    const int ph = idx / ((long)Ipad * 4 * O);
+    const int a = ph >> 1, b = ph & 1, pp = tap >> 1, q = tap & 1;
+    float acc = 0.f;
+    if (i < I)
+      for (int iy = 0; iy < 3; ++iy)
+        for (int ix = 0; ix < 3; ++ix) {
+          const int sy = a == 0 ? (iy == 0 ? 0 : 1) : (iy == 2 ? 1 : 0);
+          const int sx = b == 0 ? (ix == 0 ? 0 : 1) : (ix == 2 ? 1 : 0);
+          if (sy == pp && sx == q) acc += (float)w9[(((long)o * I + i) * 3 + iy) * 3 + ix];
+        }
+    w4[idx] = (f16)acc;
+  }
+}
+void launch_upsample_phase_w(const f16* w9, f16* w4, int O, int I, int Ipad, hipStream_t s) {
+  hipLaunchKernelGGL(k_upsample_phase_w, gs_grid((long)16 * O * Ipad), dim3(256), 0, s, w9, w4, O, I, Ipad);
+}
+
 __global__ void k_gather_rows(const f16* in, f16* out, const int* rowmap, int rows, int cols) {
   const long n = (long)rows * cols;
   GS_LOOP(idx, n) {
