@@ -58,85 +58,101 @@ __device__ __forceinline__ void pv_block(const f16* vt, int kb, int lane, const 
 }
 
 #define FA_KV 64
+#define FA_NST 3   // KV ring depth
+#define FA_QB 1    // 32-query blocks per wave (2 was measured: fewer L2->LDS bytes but occupancy 3 -> 2 waves/SIMD, net -5 %)
 
-// One KV tile of 64 keys for a wave's 32 query rows.  MASK is only instantiated for the ragged last tile, so
-// the full tiles carry no compare/select work.  Scores stay unscaled in registers; the softmax scale (times
+// One KV tile of 64 keys for a wave's FA_QB x 32 query rows.  MASK is only instantiated for the ragged last tile,
+// so the full tiles carry no compare/select work.  Scores stay unscaled in registers; the softmax scale (times
 // log2 e) is folded into the single FMA that feeds v_exp_f32.
 template <bool MASK>
-__device__ __forceinline__ void fa_tile(const f16* kt, const f16* vt, const f16x8 (&qf)[4], int lane, int kv0, int S,
-                                        float sc, float& m_run, float& l_run, f32x16 (&o)[2]) {
+__device__ __forceinline__ void fa_tile(const f16* kt, const f16* vt, const f16x8 (&qf)[FA_QB][4], int lane, int kv0, int S,
+                                        float sc, float (&m_run)[FA_QB], float (&l_run)[FA_QB], f32x16 (&o)[FA_QB][2]) {
   const int qi = lane & 31, hh = lane >> 5;
-  f32x16 s[2];
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  f16x8 kf[2][4];
+  const int L = lane & 15, db = ((lane >> 4) & 1) * 16;
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    const int row = kb * 32 + qi;   // lane's key row inside the tile
+  for (int kb = 0; kb < 2; ++kb) {           // online-softmax step per 32-key block keeps the live register set small
+    f16x8 kf[4];
+    const int row = kb * 32 + qi;            // lane's key row inside the tile
 #pragma unroll
-    for (int c = 0; c < 4; ++c) kf[kb][c] = *(const f16x8*)(kt + row * 64 + (((c * 2 + hh) ^ kswz(row)) * 8));
-  }
+    for (int c = 0; c < 4; ++c) kf[c] = *(const f16x8*)(kt + row * 64 + (((c * 2 + hh) ^ kswz(row)) * 8));
+    f16x8 pb[FA_QB][2];                       // exponentiated scores as B operands: [q block][16-key half]
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][0], qf[0], zero16, 0, 0, 0);
+    for (int qb = 0; qb < FA_QB; ++qb) {
+      f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[qb][0], zero16, 0, 0, 0);
 #pragma unroll
-    for (int c = 1; c < 4; ++c) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][c], qf[c], s[kb], 0, 0, 0);
-  }
-  float mx = -1e30f;
+      for (int c = 1; c < 4; ++c) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[c], qf[qb][c], s, 0, 0, 0);
+      float mx = -1e30f;
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (MASK) {
-        const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (key >= S) s[kb][r] = -1e30f;
+      for (int r = 0; r < 16; ++r) {
+        if (MASK) {
+          const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (key >= S) s[r] = -1e30f;
+        }
+        mx = fmaxf(mx, s[r]);
       }
-      mx = fmaxf(mx, s[kb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run[qb], mx * sc);      // running max in the scaled (log2) domain
+      if (!__all(m_new == m_run[qb])) {                    // rescale only when some row's max moved (alpha == 1 otherwise)
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+        l_run[qb] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[qb][dt][r] *= alpha;
+        m_run[qb] = m_new;
+      }
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -m_run[qb]));
+        ps += e;
+        pb[qb][r >> 3][r & 7] = (f16)e;
+      }
+      l_run[qb] += ps;
     }
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
-  const float m_new = fmaxf(m_run, mx * sc);          // running max in the scaled (log2) domain
-  if (!__all(m_new == m_run)) {                        // rescale only when some row's max moved (exact: alpha == 1 otherwise)
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    l_run *= alpha;
+    // O^T += V^T P^T : every V^T fragment (two transpose reads) feeds both query blocks
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-    m_run = m_new;
+      for (int dt = 0; dt < 2; ++dt) {
+        f16x8 va;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int vrow = kb * 32 + 16 * a + 8 * h + 4 * hh + (L >> 2);
+          const int col = dt * 32 + db + (L & 3) * 4;
+          const int chunk = (col >> 3) ^ vswz(vrow);
+          const f16x4 t = lds_tr16(vt + vrow * 64 + chunk * 8 + (col & 7));
+          va[4 * h + 0] = t[0]; va[4 * h + 1] = t[1]; va[4 * h + 2] = t[2]; va[4 * h + 3] = t[3];
+        }
+#pragma unroll
+        for (int qb = 0; qb < FA_QB; ++qb)
+          o[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pb[qb][a], o[qb][dt], 0, 0, 0);
+      }
   }
-  float pr[2][16];
-  float ps = 0.f;
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float e = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sc, -m_run));
-      pr[kb][r] = e;
-      ps += e;
-    }
-  l_run += ps;
-  pv_block(vt, 0, lane, pr[0], o);
-  pv_block(vt, 32, lane, pr[1], o);
 }
-
-#define FA_NST 3   // KV ring depth: a 64-key tile is ~0.4 us of math, far less than the load latency -> keep 3 tiles in flight
 
 __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const FlashP p) {
   __shared__ __attribute__((aligned(16))) f16 lds[FA_NST * 2 * FA_KV * 64];  // [slot][K|V][64][64]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (128 * FA_QB) + wave * (32 * FA_QB);
   const long row0 = (long)b * p.S;
   const int qi = lane & 31, hh = lane >> 5;
   const float sc = p.scale * 1.4426950408889634f;
 
-  // Q fragment (B operand of S^T = K Q^T): Q[q = qi][d = c*16 + hh*8 .. +8]
-  f16x8 qf[4];
-  const bool qok = (q0 + qi) < p.S;
+  // Q fragments (B operand of S^T = K Q^T): Q[q = qi][d = c*16 + hh*8 .. +8]
+  f16x8 qf[FA_QB][4];
+  bool qok[FA_QB];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    if (qok) qf[c] = *(const f16x8*)(p.Q + (row0 + q0 + qi) * p.ldq + h * 64 + c * 16 + hh * 8);
-    else qf[c] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  for (int qb = 0; qb < FA_QB; ++qb) {
+    qok[qb] = (q0 + qb * 32 + qi) < p.S;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (qok[qb]) qf[qb][c] = *(const f16x8*)(p.Q + (row0 + q0 + qb * 32 + qi) * p.ldq + h * 64 + c * 16 + hh * 8);
+      else qf[qb][c] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
   }
 
   // staging: 64 rows x 128 B per tile = 8 wave-instructions; wave w issues rows [w*16, w*16+16)
@@ -158,12 +174,16 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const FlashP p) {
     }
   };
 
-  f32x16 o[2];
+  f32x16 o[FA_QB][2];
+  float m_run[FA_QB], l_run[FA_QB];
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+  for (int qb = 0; qb < FA_QB; ++qb) {
+    m_run[qb] = -1e30f; l_run[qb] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[qb][dt][r] = 0.f;
+  }
 
   const int ntile = (p.S + FA_KV - 1) / FA_KV;
   const int nfull = p.S / FA_KV;
@@ -187,26 +207,30 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const FlashP p) {
     else fa_tile<true>(kt, vt, qf, lane, t * FA_KV, p.S, sc, m_run, l_run, o);
     if (++buf == FA_NST) buf = 0;
   }
-  l_run += __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_run;
-  if (qok) {
-    f16* dst = p.O + (row0 + q0 + qi) * p.ldo + h * 64;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+  for (int qb = 0; qb < FA_QB; ++qb) {
+    float l = l_run[qb];
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    if (qok[qb]) {
+      f16* dst = p.O + (row0 + q0 + qb * 32 + qi) * p.ldo + h * 64;
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        f16x4 v;
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (f16)(o[dt][r4 * 4 + e] * inv);
-        *(f16x4*)(dst + dt * 32 + 8 * r4 + 4 * hh) = v;
-      }
+        for (int r4 = 0; r4 < 4; ++r4) {
+          f16x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (f16)(o[qb][dt][r4 * 4 + e] * inv);
+          *(f16x4*)(dst + dt * 32 + 8 * r4 + 4 * hh) = v;
+        }
+    }
   }
 }
 
 void launch_flash_attn64(const FlashP& p, hipStream_t s) {
   UG_REQUIRE(p.S >= 1 && p.B >= 1 && p.H >= 1, "flash attention shape");
   UG_REQUIRE(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0, "flash attention strides");
-  dim3 grid(cdiv(p.S, 128), p.H, p.B);
+  dim3 grid(cdiv(p.S, 128 * FA_QB), p.H, p.B);
   hipLaunchKernelGGL(flash_attn64_kernel, grid, dim3(256), 0, s, p);
   UG_CHECK(hipGetLastError());
 }
