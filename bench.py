@@ -169,9 +169,11 @@ def main():
             except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
                 res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}
-        print(json.dumps(res), flush=True)
     if world > 1:
+        dist.barrier()                  # rank 0 may still be in its (un-timed) profile pass
         dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(res), flush=True)   # last line on stdout
 
 
 if __name__ == "__main__":
