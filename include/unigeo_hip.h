@@ -101,6 +101,18 @@ int ug_unet_forward(ug_ctx* ctx, const float* sample_tchw /*[T,Cin,h,w]*/, int T
 int ug_normals_from_depth(ug_ctx* ctx, const float* depth_thw, const float* intrinsics_t33, int T, int H, int W,
                           float* normals_out);
 
+/* Evaluation metrics on device.  pred == NULL uses the resident output of the last ug_dc_run
+ * (depth [T,H,W] / normals [T,H,W,3]); gt / mask are host arrays (mask: 1 byte per pixel, may be NULL).
+ *   ug_eval_depth  : replaces depth_evaluation(..., custom_mask, align_with_lstsq=True) (metrics/eval_depth.py:6-246,
+ *                    metrics/alignment.py:150-167) -> out[11] = AbsRel, SqRel, RMSE, LogRMSE, d<1, d<1.25, d<1.25^2,
+ *                    d<1.25^3, valid_pixels, scale, shift
+ *   ug_eval_normal : replaces normal_evaluation (metrics/eval_normal.py:4-72) -> out[8] = mean, median, rmse,
+ *                    %<5, %<7.5, %<11.25, %<22.5, %<30 */
+int ug_eval_depth(ug_ctx* ctx, const float* pred_depth, const float* gt_depth, const unsigned char* custom_mask, long n,
+                  float max_depth, double* out11);
+int ug_eval_normal(ug_ctx* ctx, const float* pred_normals, const float* gt_normals, const unsigned char* mask, long n,
+                   double* out8);
+
 /* Op-level entry points for kernel parity tests (row-major host matrices, fp32 in/out, computed in fp16). */
 int ug_op_linear(ug_ctx* ctx, const float* A, int M, int K, const float* W, int N, const float* bias,
                  const float* R1, float c0, float c1, int act, int geglu, float* out);

@@ -129,3 +129,45 @@ def test_full_size_invariants():
         assert_close(a, b, 5e-3, "VAE encode chunk invariance")
     finally:
         pipe.engine.close()
+
+
+def test_device_metrics_match_reference_goldens(engine):
+    """G5: the reference's own depth_evaluation(align_with_lstsq=True, custom_mask) / normal_evaluation outputs."""
+    res, (s, t_) = engine.eval_depth(G["g5_gt_d"], G["g5_mask"], pred=G["g5_pred_d"])
+    for k, v in zip(G["g5_depth_keys"], G["g5_depth_vals"]):
+        assert res[str(k)] == pytest.approx(float(v), rel=3e-5, abs=1e-6), k
+    nres = engine.eval_normal(G["g5_gt_n"], G["g5_mask"], pred=G["g5_pred_n"])
+    for k, v in zip(G["g5_normal_keys"], G["g5_normal_vals"]):
+        assert nres[str(k)] == pytest.approx(float(v), rel=3e-5, abs=2e-4), k
+
+
+def test_device_metrics_large_and_host_mirror(engine):
+    """25 x 384 x 512: device metrics == host mirror (exact median selection included)."""
+    from unigeo_amd.harness import depth_evaluation, normal_evaluation
+    rng = np.random.default_rng(5)
+    shape = (25, 384, 512)
+    gt = rng.uniform(0.3, 9.0, shape).astype(np.float32); gt[:, :5] = 0
+    pred = (1.7 * gt - 0.2 + 0.3 * rng.standard_normal(shape)).astype(np.float32)
+    mask = rng.uniform(size=shape) > 0.1
+    got, _ = engine.eval_depth(gt, mask, pred=pred)
+    ref = depth_evaluation(pred, gt, custom_mask=mask, align_with_lstsq=True)[0]
+    for k in ref:
+        assert got[k] == pytest.approx(ref[k], rel=2e-4, abs=1e-6), k
+    gn = rng.standard_normal(shape + (3,)).astype(np.float32); gn /= np.linalg.norm(gn, axis=-1, keepdims=True)
+    pn = (gn + 0.2 * rng.standard_normal(gn.shape)).astype(np.float32)
+    gotn = engine.eval_normal(gn, mask, pred=pn)
+    refn = normal_evaluation(pn, gn, custom_mask=mask)
+    for k in refn:
+        assert gotn[k] == pytest.approx(refn[k], rel=1e-4, abs=1e-3), k
+
+
+def test_harness_with_device_metrics(tiny_plugin, tmp_path):
+    from unigeo_amd.harness import SyntheticGeometryDataset, evaluate
+    cfg = {"root": "x", "h": 64, "w": 64, "clip_length": 3, "clip_overlap": 1,
+           "eval_depth": {"metric_names": ["Abs Rel", "delta < 1.25"]}, "eval_normal": {"metric_names": ["normal mean", "normal median"]}}
+    ds = SyntheticGeometryDataset(clip_length=3, clip_overlap=1, input_size=(64, 64), num_frames=5)
+    host, _ = evaluate(cfg, dataset=ds, model=tiny_plugin, save_dir=str(tmp_path / "h"), verbose=False)
+    dev, _ = evaluate(cfg, dataset=ds, model=tiny_plugin, save_dir=str(tmp_path / "d"), verbose=False, device_metrics=True)
+    for a, b in zip(host, dev):
+        for k in ("Abs Rel", "delta < 1.25", "normal mean", "normal median"):
+            assert b[k] == pytest.approx(a[k], rel=2e-4, abs=1e-3), k

@@ -19,7 +19,7 @@ EXPORTS = [
     "ug_create", "ug_destroy", "ug_last_error", "ug_workspace_peak",
     "ug_load_tensor", "ug_bind_unet", "ug_bind_vae", "ug_bind_clip",
     "ug_dc_set_inputs", "ug_dc_run", "ug_dc_get_outputs", "ug_dc_device_ptrs",
-    "ug_clip_embed", "ug_vae_encode", "ug_vae_decode", "ug_unet_forward", "ug_normals_from_depth",
+    "ug_eval_depth", "ug_eval_normal", "ug_clip_embed", "ug_vae_encode", "ug_vae_decode", "ug_unet_forward", "ug_normals_from_depth",
     "ug_op_linear", "ug_op_conv", "ug_op_groupnorm", "ug_op_layernorm", "ug_op_flash_attn",
     "ug_op_temporal_attn", "ug_op_attention_generic", "ug_op_euler_step",
     "ug_profile_begin", "ug_profile_begin_shapes", "ug_profile_end", "ug_bench_gemm", "ug_tune_force",
@@ -78,6 +78,8 @@ def load_library():
     lib.ug_dc_run.argtypes = [vp, ip, ip, ip]
     lib.ug_dc_get_outputs.argtypes = [vp, vp, vp, vp]
     lib.ug_dc_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.ug_eval_depth.argtypes = [vp, vp, vp, vp, C.c_long, C.c_float, vp]
+    lib.ug_eval_normal.argtypes = [vp, vp, vp, vp, C.c_long, vp]
     lib.ug_clip_embed.argtypes = [vp, vp, ip, ip, ip, vp]
     lib.ug_vae_encode.argtypes = [vp, vp, ip, ip, ip, vp]
     lib.ug_vae_decode.argtypes = [vp, vp, ip, ip, ip, vp]
@@ -246,6 +248,28 @@ class Engine:
         out = np.empty((T, H, W, 3), np.float32)
         self._ck(self.lib.ug_normals_from_depth(self.ctx, _ptr(d), _ptr(k), T, H, W, _ptr(out)))
         return out
+
+    # ---- metrics on device (pred=None: use the resident outputs of the last run)
+    DEPTH_KEYS = ["Abs Rel", "Sq Rel", "RMSE", "Log RMSE", "delta < 1.", "delta < 1.25", "delta < 1.25^2", "delta < 1.25^3"]
+    NORMAL_KEYS = ["normal mean", "normal median", "normal rmse", "angle < 5", "angle < 7.5", "angle < 11.25", "angle < 22.5", "angle < 30"]
+
+    def eval_depth(self, gt, mask=None, pred=None, max_depth=80.0):
+        g = _f32(gt); n = g.size
+        p = None if pred is None else _f32(pred)
+        m = None if mask is None else np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+        out = np.zeros(11, np.float64)
+        self._ck(self.lib.ug_eval_depth(self.ctx, _ptr(p), _ptr(g), _ptr(m), n, float(max_depth), _ptr(out)))
+        res = dict(zip(self.DEPTH_KEYS, out[:8].tolist()))
+        res["valid_pixels"] = int(out[8])
+        return res, (float(out[9]), float(out[10]))
+
+    def eval_normal(self, gt, mask=None, pred=None):
+        g = _f32(gt); n = g.size // 3
+        p = None if pred is None else _f32(pred)
+        m = None if mask is None else np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+        out = np.zeros(8, np.float64)
+        self._ck(self.lib.ug_eval_normal(self.ctx, _ptr(p), _ptr(g), _ptr(m), n, _ptr(out)))
+        return dict(zip(self.NORMAL_KEYS, out.tolist()))
 
     # ---- ops (parity tests)
     def op_linear(self, A, W, bias=None, R1=None, c0=1.0, c1=1.0, act=0, geglu=False):

@@ -1,4 +1,5 @@
 // extern "C" surface of libunigeo_hip.so (declared in include/unigeo_hip.h).
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -247,6 +248,82 @@ int ug_normals_from_depth(ug_ctx* x, const float* depth, const float* K, int T, 
     launch_normals(dd, dk, dn, T, H, W, c.stream);
     UG_CHECK(hipStreamSynchronize(c.stream));
     UG_CHECK(hipMemcpy(normals, dn, px * 3 * 4, hipMemcpyDeviceToHost));
+  });
+}
+
+int ug_eval_depth(ug_ctx* x, const float* pred, const float* gt, const unsigned char* cmask, long n, float max_depth, double* out) {
+  UG_TRY(x, {
+    Ctx& c = x->c; Scope sc(c);
+    const float* dp;
+    if (pred) { float* d = c.ws.get<float>(n); UG_CHECK(hipMemcpy(d, pred, n * 4, hipMemcpyHostToDevice)); dp = d; }
+    else { UG_REQUIRE(c.io_ready && n == (long)c.T * c.H * c.W, "no resident depth of that size"); dp = c.d_depth; }
+    float* dg = c.ws.get<float>(n); UG_CHECK(hipMemcpy(dg, gt, n * 4, hipMemcpyHostToDevice));
+    unsigned char* dm = nullptr;
+    if (cmask) { dm = (unsigned char*)c.ws.alloc(n); UG_CHECK(hipMemcpy(dm, cmask, n, hipMemcpyHostToDevice)); }
+    double* part = c.ws.get<double>(1024 * 9);
+    std::vector<double> h(1024 * 9);
+    int nb = 0;
+    launch_depth_fit(dp, dg, n, max_depth, part, &nb, c.stream);
+    UG_CHECK(hipStreamSynchronize(c.stream));
+    UG_CHECK(hipMemcpy(h.data(), part, (size_t)nb * 5 * 8, hipMemcpyDeviceToHost));
+    double a[5] = {0, 0, 0, 0, 0};
+    for (int b = 0; b < nb; ++b) for (int k = 0; k < 5; ++k) a[k] += h[b * 5 + k];
+    // least squares of g ~ s*p + t:  [sum p^2, sum p; sum p, n] [s; t] = [sum pg; sum g]
+    const double det = a[2] * a[0] - a[1] * a[1];
+    UG_REQUIRE(a[0] >= 2 && fabs(det) > 0, "degenerate depth alignment (fewer than 2 valid pixels or constant prediction)");
+    const double s_ = (a[4] * a[0] - a[1] * a[3]) / det, t_ = (a[2] * a[3] - a[1] * a[4]) / det;
+    launch_depth_metrics(dp, dg, dm, n, max_depth, (float)s_, (float)t_, part, &nb, c.stream);
+    UG_CHECK(hipStreamSynchronize(c.stream));
+    UG_CHECK(hipMemcpy(h.data(), part, (size_t)nb * 9 * 8, hipMemcpyDeviceToHost));
+    double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < nb; ++b) for (int k = 0; k < 9; ++k) m[k] += h[b * 9 + k];
+    const double cnt = m[0];
+    if (cnt > 0) {
+      out[0] = m[1] / cnt; out[1] = m[2] / cnt; out[2] = sqrt(m[3] / cnt); out[3] = sqrt(m[4] / cnt);
+      for (int k = 0; k < 4; ++k) out[4 + k] = m[5 + k] / cnt;
+    } else { for (int k = 0; k < 8; ++k) out[k] = 0; }
+    out[8] = cnt; out[9] = s_; out[10] = t_;
+  });
+}
+
+int ug_eval_normal(ug_ctx* x, const float* pred, const float* gt, const unsigned char* mask, long n, double* out) {
+  UG_TRY(x, {
+    Ctx& c = x->c; Scope sc(c);
+    const float* dp;
+    if (pred) { float* d = c.ws.get<float>(n * 3); UG_CHECK(hipMemcpy(d, pred, n * 12, hipMemcpyHostToDevice)); dp = d; }
+    else { UG_REQUIRE(c.io_ready && n == (long)c.T * c.H * c.W, "no resident normals of that size"); dp = c.d_normals; }
+    float* dg = c.ws.get<float>(n * 3); UG_CHECK(hipMemcpy(dg, gt, n * 12, hipMemcpyHostToDevice));
+    unsigned char* dm = nullptr;
+    if (mask) { dm = (unsigned char*)c.ws.alloc(n); UG_CHECK(hipMemcpy(dm, mask, n, hipMemcpyHostToDevice)); }
+    float* err = c.ws.get<float>(n);
+    double* part = c.ws.get<double>(1024 * 8);
+    unsigned* hist = (unsigned*)c.ws.alloc(4097 * 4);
+    UG_CHECK(hipMemsetAsync(hist, 0, 4097 * 4, c.stream));
+    int nb = 0;
+    launch_normal_err(dp, dg, dm, n, err, part, hist, &nb, c.stream);
+    UG_CHECK(hipStreamSynchronize(c.stream));
+    std::vector<double> h((size_t)nb * 8);
+    std::vector<unsigned> hh(4096);
+    UG_CHECK(hipMemcpy(h.data(), part, (size_t)nb * 8 * 8, hipMemcpyDeviceToHost));
+    UG_CHECK(hipMemcpy(hh.data(), hist, 4096 * 4, hipMemcpyDeviceToHost));
+    double m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < nb; ++b) for (int k = 0; k < 8; ++k) m[k] += h[b * 8 + k];
+    const long cnt = (long)m[0];
+    UG_REQUIRE(cnt > 0, "normal evaluation: empty mask");
+    // torch.median = lower median = element (cnt-1)/2 of the sorted errors: find its bin, then sort that bin only
+    const long kth = (cnt - 1) / 2;
+    long acc = 0; int bin = 0;
+    for (; bin < 4096; ++bin) { if (acc + hh[bin] > kth) break; acc += hh[bin]; }
+    const unsigned cap = hh[bin];
+    float* binv = c.ws.get<float>(cap);
+    unsigned* cntd = hist + 4096;
+    launch_collect_bin(err, n, bin, binv, cntd, cap, c.stream);
+    UG_CHECK(hipStreamSynchronize(c.stream));
+    std::vector<float> bv(cap);
+    UG_CHECK(hipMemcpy(bv.data(), binv, (size_t)cap * 4, hipMemcpyDeviceToHost));
+    std::sort(bv.begin(), bv.end());
+    out[0] = m[1] / cnt; out[1] = bv[kth - acc]; out[2] = sqrt(m[2] / cnt);
+    for (int k = 0; k < 5; ++k) out[3 + k] = 100.0 * m[3 + k] / cnt;
   });
 }
 

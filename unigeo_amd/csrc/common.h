@@ -160,3 +160,13 @@ void launch_depth_post(const float* frames, float* depth, float* minmax_ws, long
                        hipStream_t s);        // channel mean, clip-global min-max, 1/(x+0.1)
 void launch_normals(const float* depth, const float* K33, float* normals, int T, int H, int W,
                     hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// Evaluation metrics on device (kernels/metrics.hip)
+// ---------------------------------------------------------------------------------------
+void launch_depth_fit(const float* pred, const float* gt, long n, float max_depth, double* part, int* nb, hipStream_t s);
+void launch_depth_metrics(const float* pred, const float* gt, const unsigned char* cmask, long n, float max_depth, float sc,
+                          float sh, double* part, int* nb, hipStream_t s);
+void launch_normal_err(const float* pn, const float* gn, const unsigned char* mask, long n, float* err, double* part,
+                       unsigned* hist, int* nb, hipStream_t s);
+void launch_collect_bin(const float* err, long n, int bin, float* out, unsigned* count, unsigned cap, hipStream_t s);
