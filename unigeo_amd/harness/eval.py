@@ -36,7 +36,7 @@ def evaluate(config, dataset=None, model=None, save_dir="./debug_output", rank=0
     ``device_metrics=True`` evaluates depth / normal metrics on the GPU against the outputs still resident in HBM
     (``ug_eval_depth`` / ``ug_eval_normal``) instead of on the host copies."""
     if dataset is None:
-        dataset = import_class_from_module("unigeo_amd.harness.dataset", config["dataset"])(**parse_dataset_config(config))
+        dataset = import_class_from_module("unigeo_amd.harness", config["dataset"])(**parse_dataset_config(config))
     if model is None:
         model = import_class_from_module("unigeo_amd.model", config["model_name"])(**config["model_params"])
     mm = MetricsManager(metric_names=parse_metric_config(config))
