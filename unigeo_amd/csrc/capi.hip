@@ -481,6 +481,7 @@ int ug_bench_gemm(ug_ctx* x, int M, int N, int K, int conv, int T, int Hi, int W
     p.M = M; p.N = N; p.K = K; p.W = Wt; p.ldw = K; p.bias = b; p.c0 = 1.f; p.ldo = N;
     p.zero = c.zero; p.nb_inner = 1;
     p.A0 = As[0]; p.A1 = A1s[0]; p.Out = Os[0];
+    if (getenv("UG_BENCH_GEGLU") && !conv && N % 128 == 0) { p.flags |= UG_F_GEGLU; p.ldo = N / 2; }   // A/B aid: GEGLU epilogue
     int cf = cfg, sp = split;
     if (cf < 0 || sp < 1) { int c2, s2; gemm_plan(p, 1, &c2, &s2); if (cf < 0) cf = c2; if (sp < 1) sp = s2; }
     p.cfg_p1 = cf + 1; p.splitk = sp;

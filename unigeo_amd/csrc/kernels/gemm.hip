@@ -52,8 +52,17 @@ template <int BM, int BN, int BK, int NST, int WMW, int WNW> struct GemmOcc {
   static constexpr int wps = wps_raw < 1 ? 1 : (wps_raw > 4 ? 4 : wps_raw);
 };
 
-template <int BM, int BN, int BK, int NST, int WMW, int WNW, bool CONV, bool UNI>
+// BUFA: operands are fetched with buffer addressing (buffer_load_dwordx4 ... offen lds): the per-lane byte offset of a
+// row is computed once per tile, the K / tap advance is a scalar offset, and out-of-range rows / padding taps point the
+// lane past num_records, where the hardware returns zeros.  That takes the ~16 VALU instructions per load that the
+// 64-bit flat addressing (pointer arithmetic + zero-page select) costs down to a compare-and-select; measured with
+// SQ_ACTIVE_INST_VALU that address arithmetic was ~1/4 of a K-step on the 8-wave tiles and more on the small ones.
+// Requires 32-bit offsets (operands < 2 GiB), whole K tiles (dense K % BK == 0) and, for im2col, the single-tap-per-
+// K-tile form without the nearest-2x source mapping; launch_mode checks this and otherwise uses the flat-address form.
+template <int BM, int BN, int BK, int NST, int WMW, int WNW, bool CONV, bool UNI, bool BUFA = false>
 __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>::wps)) void gemm_kernel(const GemmP p) {
+  static_assert(!BUFA || !CONV || UNI, "buffer addressing needs the single-tap K tiles");
+  constexpr unsigned SENT = 0x80000000u;   // == num_records: every lane offset >= SENT reads zeros
   constexpr int NWAVE = WMW * WNW;
   constexpr int WTM = BM / WMW, WTN = BN / WNW;     // wave tile
   constexpr int MT = WTM / 16, NT = WTN / 16;       // MFMA tiles per wave
@@ -107,6 +116,15 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
   const bool fastconv = CONV && UNI;
   int a_par[AI];                        // ups == 2: parity bits (y&1)<<1 | (x&1) of the row's first tap in upsampled coords
   int b_lc[BI]; const f16* b_ptr[BI]; bool b_ok[BI];
+  unsigned a_off[AI], a_off1[AI], b_off[BI];   // BUFA: byte offsets from the (shifted) operand bases, or SENT
+  // im2col: the base is moved back by the largest negative tap displacement so that every row offset is >= 0
+  const int cshift = CONV ? ((p.kt >> 1) * p.Hi + p.pad_t) * p.Wi + p.pad_l : 0;
+  __amdgpu_buffer_rsrc_t rA0, rA1, rW;
+  if (BUFA) {
+    rA0 = __builtin_amdgcn_make_buffer_rsrc((void*)(A0 - (long)cshift * p.C0), 0, (int)SENT, 0x00020000);
+    rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)((CONV && p.A1) ? p.A1 - (long)cshift * p.C1 : A0), 0, (int)SENT, 0x00020000);
+    rW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, (int)SENT, 0x00020000);
+  }
 #pragma unroll
   for (int j = 0; j < AI; ++j) a_lc[j] = pc ^ swz<BK>((wave * AI + j) * RPI + lrow);
 #pragma unroll
@@ -134,7 +152,11 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
                 if (tt >= 0 && tt < p.T && y >= 0 && y < p.Hi * p.ups && x >= 0 && x < p.Wi * p.ups) mk |= 1u << bit;
               }
           a_mask[j] = a_ok[j] ? mk : 0u;
-          if (p.ups == 1) {
+          if (BUFA) {
+            const unsigned ap = (unsigned)(((t - (p.kt >> 1)) * p.Hi + a_y[j]) * p.Wi + a_x[j] + cshift);
+            a_off[j] = ap * (unsigned)(p.C0 * 2) + a_lc[j] * 16;
+            a_off1[j] = ap * (unsigned)(p.C1 * 2) + a_lc[j] * 16;
+          } else if (p.ups == 1) {
             a_pix[j] = ((t - (p.kt >> 1)) * p.Hi + a_y[j]) * p.Wi + a_x[j];
             a_par[j] = 0;
           } else {   // nearest-2x source: pixel of tap (iy,ix) = base + ((iy+py)>>1)*Wi + ((ix+px)>>1)
@@ -145,6 +167,7 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
       } else {
         a_ptr[j] = A0 + (long)m * p.C0;
         a_t[j] = a_y[j] = a_x[j] = 0;
+        if (BUFA) a_off[j] = (a_ok[j] && kt_lo < kt_hi) ? (unsigned)m * (unsigned)(p.C0 * 2) + a_lc[j] * 16 : SENT;
       }
     }
 #pragma unroll
@@ -155,6 +178,7 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
       const int n = n0 + part * WTN + (i >> 2) * WID + jj * 4 + (i & 3);
       b_ok[j] = n < p.N;
       b_ptr[j] = Wb + (long)n * p.ldw;
+      if (BUFA) b_off[j] = (b_ok[j] && kt_lo < kt_hi) ? (unsigned)n * (unsigned)(p.ldw * 2) + b_lc[j] * 16 : SENT;
     }
   };
 
@@ -181,6 +205,15 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
         const bool src0 = cb < p.C0;               // C0 % BK == 0 is checked by the launcher: a K tile never straddles
         const f16* base = src0 ? A0 : p.A1;
         const int Cs = src0 ? p.C0 : p.C1, c0 = src0 ? cb : cb - p.C0;
+        if (BUFA) {
+          const int soff = (tappix * Cs + c0) * 2;
+          const __amdgpu_buffer_rsrc_t rs = src0 ? rA0 : rA1;
+#pragma unroll
+          for (int j = 0; j < AI; ++j) {
+            const unsigned voff = ((a_mask[j] >> tapbit) & 1u) ? (src0 ? a_off[j] : a_off1[j]) : SENT;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(As + (wave * AI + j) * RPI * BK), 16, (int)voff, soff, 0, 0);
+          }
+        } else
 #pragma unroll
         for (int j = 0; j < AI; ++j) {
           const bool ok = (a_mask[j] >> tapbit) & 1u;
@@ -192,7 +225,12 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
       u_cb += BK;
       if (u_cb >= Cin) { u_cb = 0; if (++u_ix == p.kx) { u_ix = 0; if (++u_iy == p.ky) { u_iy = 0; ++u_it; } } }
     }
-    if (!fastconv)
+    if (BUFA && !CONV) {
+#pragma unroll
+      for (int j = 0; j < AI; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, (lptr_t)(As + (wave * AI + j) * RPI * BK), 16, (int)a_off[j], kt0 * 2, 0, 0);
+    }
+    if (!fastconv && !(BUFA && !CONV))
 #pragma unroll
     for (int j = 0; j < AI; ++j) {
       const f16* src = p.zero;
@@ -221,6 +259,11 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
       }
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (wave * AI + j) * RPI * BK), 16, 0, 0);
     }
+    if (BUFA) {
+#pragma unroll
+      for (int j = 0; j < BI; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(Bs + (wave * BI + j) * RPI * BK), 16, (int)b_off[j], kt0 * 2, 0, 0);
+    } else
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
       const int k = kt0 + b_lc[j] * 8;
@@ -474,11 +517,11 @@ __global__ __launch_bounds__(256) void splitk_epilogue(const GemmP p) {
 }
 
 int gemm_knobs_get();
-template <int BM, int BN, int BK, int NST, int WMW, int WNW, bool CONV, bool UNI>
+template <int BM, int BN, int BK, int NST, int WMW, int WNW, bool CONV, bool UNI, bool BUFA = false>
 static void launch_t(const GemmP& p, int batch, hipStream_t s) {
   const int ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
   const size_t lds = (size_t)NST * (BM + BN) * BK * sizeof(f16);
-  auto kern = gemm_kernel<BM, BN, BK, NST, WMW, WNW, CONV, UNI>;
+  auto kern = gemm_kernel<BM, BN, BK, NST, WMW, WNW, CONV, UNI, BUFA>;
   static int per_cu = 0;
   if (!per_cu) {
     if (lds > 64 * 1024) UG_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -496,12 +539,20 @@ static void launch_t(const GemmP& p, int batch, hipStream_t s) {
 
 template <int BM, int BN, int BK, int NST, int WMW, int WNW>
 static void launch_mode(const GemmP& p, int batch, hipStream_t s) {
+  const long lim = (1L << 31) - 64;   // buffer addressing: every byte offset must stay below num_records
+  const bool bufw = (long)p.N * p.ldw * 2 < lim && !(gemm_knobs_get() & 4);
   if (p.conv) {
     const bool uni = ((p.C0 + p.C1) % BK) == 0 && (p.C0 % BK) == 0 && p.kt * p.ky * p.kx <= 32;
-    if (uni) launch_t<BM, BN, BK, NST, WMW, WNW, true, true>(p, batch, s);
+    const long px = (long)p.T * p.Hi * p.Wi + ((long)(p.kt >> 1) * p.Hi + p.pad_t) * p.Wi + p.pad_l + 1;
+    const bool bufa = bufw && uni && p.ups == 1 && px * p.C0 * 2 < lim && px * p.C1 * 2 < lim;
+    if (uni && bufa) launch_t<BM, BN, BK, NST, WMW, WNW, true, true, true>(p, batch, s);
+    else if (uni) launch_t<BM, BN, BK, NST, WMW, WNW, true, true>(p, batch, s);
     else launch_t<BM, BN, BK, NST, WMW, WNW, true, false>(p, batch, s);
   } else {
-    launch_t<BM, BN, BK, NST, WMW, WNW, false, false>(p, batch, s);
+    // dense: measured +4-6 % on the 8-wave tiles, -1..-4 % on the 4-wave 128x64 / 256x64 ones (profiles/r01_gemm_buffer_addressing.txt)
+    const bool bufa = bufw && p.K % BK == 0 && (long)p.M * p.C0 * 2 < lim && (BM * BN >= 256 * 128 || (gemm_knobs_get() & 8));
+    if (bufa) launch_t<BM, BN, BK, NST, WMW, WNW, false, false, true>(p, batch, s);
+    else launch_t<BM, BN, BK, NST, WMW, WNW, false, false>(p, batch, s);
   }
 }
 
@@ -523,40 +574,57 @@ static void launch_cfg(int cfg, const GemmP& p, int batch, hipStream_t s) {
   }
 }
 
-static int g_force_cfg = -1, g_force_split = -1, g_knobs = 0;   // knobs: 1 = one tile per workgroup, 2 = no XCD remap
+static int g_force_cfg = -1, g_force_split = -1, g_knobs = 0;   // knobs: 1 = one tile per workgroup, 2 = no XCD remap, 4 = flat addressing only
 void gemm_force(int cfg, int split) { if (cfg <= -100) { g_knobs = -cfg - 100; return; } g_force_cfg = cfg; g_force_split = split; }
 
 
 
 int gemm_knobs_get() { return g_knobs; }
 
-// heuristic (measured on MI355X with tools/tune_gemm.py): returns tile config and split-K factor
-//   cfg 1 (128x64x64, 3 WG/CU)  : N < 2048 dense (short K, narrow N: more co-resident workgroups hide the
-//                                 per-tile prologue/epilogue) and the UNet-level convolutions
-//   cfg 14 (256x64x64, 8 waves) : the same shapes at the full-resolution UNet level (M = 76800)
-//   cfg 15 (256x256x64, 8 waves, 128x64 wave tiles) : wide outputs - GEGLU / N >= 2048 projections and the
-//                                 256/512-channel VAE convolutions (halves the LDS + L2 bytes per FLOP)
-//   cfg 0 (128x128x64, 2 WG/CU) : wide dense (GEGLU projections, CLIP MLP), the VAE's big convolutions, split-K
+// Tile planner.  For every candidate tile the attainable rate is modelled as
+//     base(cfg) x (M, N edge-tile utilisation) x (fill of the last round of the persistent grid)
+// with base = the rate measured on a large, exactly tiling problem (tools/tune_gemm.py, profiles/r01_gemm_tile_tuning.txt:
+// 8192^3 dense, the 512-channel VAE conv for im2col).  Checked against the full sweep of the clip's shapes the model's
+// pick is the measured best or within ~5 % of it.  Low-resolution levels (M <= 2048) are latency-bound, not
+// throughput-bound: they keep the measured rules below (64x64 tiles / split-K).
+struct TileCand { int id, bm, bn, percu; float dense, conv; bool geglu_ok; };
+static const TileCand kCands[] = {
+    {15, 256, 256, 1, 1200.f, 1130.f, true},  {19, 256, 128, 1, 1050.f, 929.f, false}, {0, 128, 128, 2, 890.f, 1025.f, true},
+    {14, 256, 64, 2, 880.f, 883.f, false},    {1, 128, 64, 3, 757.f, 799.f, false},    {12, 64, 64, 5, 456.f, 652.f, false}};
+
 void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
   const bool geglu = p.flags & UG_F_GEGLU;
-  int cfg;
-  if (geglu) cfg = 15;
-  else if (p.conv)
-    cfg = ((p.M >= 90000 && p.N % 256 == 0) || (p.M >= 16384 && p.N >= 512)) ? 15
-          : (p.M >= 90000 && p.N == 128) ? 19 : (p.M >= 90000 && p.N % 128 == 0) ? 0 : (p.M >= 50000 ? 14 : 1);
-  else
-    cfg = (p.N >= 2048 || (p.M >= 16384 && p.N >= 512 && p.K >= 2048)) ? 15 : (p.M >= 50000 ? 14 : 1);
+  int cfg = 15;
+  float best = -1.f;
+  for (const TileCand& c : kCands) {
+    if (geglu && !c.geglu_ok) continue;
+    const long tm = cdiv(p.M, c.bm), tn = cdiv(p.N, c.bn);
+    const long tiles = tm * tn * batch, slots = (long)c.percu * 256;
+    float sc = (p.conv ? c.conv : c.dense) * ((float)p.M / (tm * c.bm)) * ((float)p.N / (tn * c.bn)) *
+               ((float)tiles / (cdiv(tiles, slots) * slots));
+    if (c.id == 19 && p.K <= 512) sc *= 1.15f;   // its 3-stage ring hides the short K loop's fill better (temporal convs, K = 3C)
+    if (sc > best) { best = sc; cfg = c.id; }
+  }
   int split = 1;
   const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * batch;
   const int nk = cdiv(p.K, 64);
   const bool plain_epi = !geglu && !p.up_phase && !(p.flags & UG_F_OUT_F32) && batch == 1 && (p.N % 8 == 0) && (p.ldo % 8 == 0) &&
                          (!p.R1 || p.ldr1 % 8 == 0) && (!p.R2 || p.ldr2 % 8 == 0);
-  if (plain_epi && tiles128 <= 128 && nk >= 64 && p.N >= 128) {   // under half a wave of workgroups and a long K loop
-    split = (int)std::min<long>(8, std::max<long>(1, 768 / tiles128));
-    split = std::min(split, nk / 16);
-    if (split < 2) split = 1; else cfg = 0;
+  // Latency-bound corner (tools/tune_splitk.py): few tiles, long K loops.  Split-K over the 128x128 tile with the largest
+  // factor whose persistent grid (512 / split workgroups, rounded down to a multiple of 8) still holds every tile in one round;
+  // mid-length K loops do better with two slices of the 3-stage 128x64 tile.
+  if (!geglu && p.M <= 2048 && p.N < 2048) {
+    cfg = 3;
+    if (plain_epi && p.N >= 128) {
+      if (nk >= 128) {
+        for (int sp = 8; sp >= 2; --sp)
+          if ((512 / sp) / 8 * 8 >= tiles128 && nk / sp >= 16) { split = sp; cfg = 0; break; }
+      }
+      if (split == 1 && nk >= 48) split = 2;
+    }
+  } else if (plain_epi && p.conv && p.M <= 8192 && nk >= 256 && p.N >= 512) {
+    cfg = 0; split = 4;   // 12x16 level, concatenated 2560-channel input: four K slices fill the last round (880 vs 816 TFLOP/s)
   }
-  if (split == 1 && !geglu && p.M <= 2048 && p.N < 2048) cfg = 12;   // lowest-resolution level: 64x64 tiles fill more CUs
   if (g_force_cfg >= 0) cfg = g_force_cfg;
   if (g_force_split >= 0) split = plain_epi ? std::max(1, g_force_split) : 1;
   *cfg_out = cfg; *split_out = split;
