@@ -35,6 +35,27 @@ __device__ __forceinline__ float erf_as(float x) {
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
+// GEGLU on two (value, gate) pairs in packed fp32 (v_pk_fma/mul/add_f32 issue two lanes' worth per instruction):
+//   h * g * Phi(g),  Phi(g) = 1/2 + sign(g) (1/2 - erfc(|g|/sqrt2)/2),  erfc by the same Abramowitz-Stegun 7.1.26 form as
+// erf_as (coefficients pre-halved, argument scaling folded in).  Per pair of outputs: 2 rcp + 2 exp2 + ~16 VALU instead of
+// ~50 for the scalar form - in the K = 320 projections the epilogue is as long as the K loop, so this is wall time.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 geglu2(f32x2 h, f32x2 g) {
+  const f32x2 ag = {__builtin_fabsf(g.x), __builtin_fabsf(g.y)};
+  const f32x2 u = ag * 0.23164189f + 1.0f;   // 1 + 0.3275911 |g| / sqrt(2)
+  const f32x2 t = {__builtin_amdgcn_rcpf(u.x), __builtin_amdgcn_rcpf(u.y)};
+  f32x2 y = t * 0.5307027145f - 0.7265760135f;
+  y = y * t + 0.7107068705f;
+  y = y * t - 0.142248368f;
+  y = y * t + 0.127414796f;
+  y = y * t;                                   // erfc(|g|/sqrt2) / 2 / exp(-g^2/2)
+  const f32x2 w = (g * g) * -0.72134752044f;   // -g^2/2 * log2(e)
+  const f32x2 e = {__builtin_amdgcn_exp2f(w.x), __builtin_amdgcn_exp2f(w.y)};
+  const f32x2 q = 0.5f - y * e;
+  const f32x2 phi = {0.5f + __builtin_copysignf(q.x, g.x), 0.5f + __builtin_copysignf(q.y, g.y)};
+  return h * g * phi;
+}
+
 // 16-byte-chunk swizzle of a [rows][BK] fp16 LDS tile: makes 16 consecutive rows reading the same logical
 // chunk land on 16 distinct 16-byte slots of the 256-byte bank row.
 template <int BK> __device__ __forceinline__ int swz(int row) {
@@ -420,7 +441,10 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
       if (geglu) {
         if (WID == 16) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = v[e] * gelu_f(v[8 + e]);
+          for (int e = 0; e < 8; e += 2) {
+            const f32x2 r = geglu2((f32x2){v[e], v[e + 1]}, (f32x2){v[8 + e], v[9 + e]});
+            v[e] = r.x; v[e + 1] = r.y;
+          }
         }
       }
       if (vec) {
@@ -602,7 +626,7 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
     const long tiles = tm * tn * batch, slots = (long)c.percu * 256;
     float sc = (p.conv ? c.conv : c.dense) * ((float)p.M / (tm * c.bm)) * ((float)p.N / (tn * c.bn)) *
                ((float)tiles / (cdiv(tiles, slots) * slots));
-    if (c.id == 19 && p.K <= 512) sc *= 1.15f;   // its 3-stage ring hides the short K loop's fill better (temporal convs, K = 3C)
+    if (c.id == 19 && p.conv && p.K <= 512) sc *= 1.15f;   // its 3-stage ring hides the short K loop's fill (temporal convs, K = 3C); in-situ it loses on dense K = 320
     if (sc > best) { best = sc; cfg = c.id; }
   }
   int split = 1;
@@ -625,7 +649,7 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
   } else if (plain_epi && p.conv && p.M <= 8192 && nk >= 256 && p.N >= 512) {
     cfg = 0; split = 4;   // 12x16 level, concatenated 2560-channel input: four K slices fill the last round (880 vs 816 TFLOP/s)
   }
-  if (g_force_cfg >= 0) cfg = g_force_cfg;
+  if (g_force_cfg >= 0 && !(geglu && g_force_cfg != 0 && g_force_cfg != 4 && g_force_cfg != 8 && g_force_cfg != 15)) cfg = g_force_cfg;
   if (g_force_split >= 0) split = plain_epi ? std::max(1, g_force_split) : 1;
   *cfg_out = cfg; *split_out = split;
 }
