@@ -294,3 +294,79 @@ def test_flash_attention_full_size_properties(engine):
     x[:, :, 1:] = x[:, perm][:, :, 1:]                       # permute K and V rows together, keep Q
     got2 = engine.op_flash_attn(x.reshape(B * S, -1), B, H, S)
     assert_close(got2, got, 1e-3, "key-permutation invariance")
+
+
+# ---------------------------------------------------------------------------------------------------
+# Cross-config race screen.  Every tile configuration accumulates K through the same 16x16x32 MFMA chain in the same
+# order, so (split-K aside) all of them must produce bit-identical outputs; a pipeline race in one kernel variant
+# (ring slot reuse, counted vmcnt, the asymmetric-loader kernels = configs 34 / 35 / 39) shows up as a difference.
+# ---------------------------------------------------------------------------------------------------
+def _force(engine, cfg):
+    engine.lib.ug_tune_force(cfg, 1 if cfg >= 0 else -1)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 3, 4, 8, 12, 14, 19, 34, 35, 39])
+def test_tile_configs_bitwise_identical_small_ragged(engine, cfg):
+    rng = np.random.default_rng(100 + cfg)
+    geglu = cfg in (0, 4, 8, 35)
+    M, K, N = 2049, 1352 if cfg < 30 else 1344, 640          # ragged M (and K where the flat-address path is taken)
+    A, W, b, R = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5), rnd(rng, N), rnd(rng, M, N // 2 if geglu else N)
+    x, x1 = rnd(rng, 5, 20, 28, 128), rnd(rng, 5, 20, 28, 64)
+    w = rnd(rng, 192, 192, 1, 3, 3, scale=(9 * 192) ** -0.5)
+    wt = rnd(rng, 192, 128, 3, 1, 1, scale=(3 * 128) ** -0.5)
+    bc = rnd(rng, 192)
+    w128 = np.ascontiguousarray(w[:, :128])
+
+    def run():
+        return (engine.op_linear(A, W, b, R1=R, geglu=geglu), engine.op_conv(x, w, bc, x1=x1), engine.op_conv(x, w128, bc, ups=2),
+                engine.op_conv(x, wt, bc, kt=3, k=1, pad_t=0, pad_l=0), engine.op_conv(x, w128, bc, stride=2),
+                engine.op_conv(x, w128, bc, stride=2, pad_t=0, pad_l=0))
+    try:
+        _force(engine, 15)
+        ref = run()
+        _force(engine, cfg)
+        for rep in range(2):
+            for i, (g_, r_) in enumerate(zip(run(), ref)):
+                assert np.array_equal(g_, r_), f"cfg {cfg} output {i} run {rep}: max diff {np.abs(g_ - r_).max()}"
+    finally:
+        _force(engine, -1)
+    rows = _rows(rng, M, 32)
+    y = t(A[rows] @ W.T + b)
+    if geglu:
+        h, g2 = y.chunk(2, dim=-1)
+        y = h * F.gelu(g2)
+    assert_close(ref[0][rows], y.numpy() + R[rows], TOL, "config 15 reference itself")
+    assert_close(ref[1], conv_ref(np.concatenate([x, x1], -1), w.reshape(192, 192, 3, 3), bc), TOL, "config 15 conv reference itself")
+
+
+@pytest.mark.parametrize("M,K,N,geglu", [(76800, 320, 2560, True), (19200, 2560, 640, False), (4800, 5120, 1280, False)])
+def test_loader_kernel_bitwise_full_size_dense(engine, M, K, N, geglu):
+    rng = np.random.default_rng(M + K)
+    A, W, b = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5), rnd(rng, N)
+    try:
+        _force(engine, 15)
+        ref = engine.op_linear(A, W, b, geglu=geglu)
+        _force(engine, 35)
+        for rep in range(3):
+            got = engine.op_linear(A, W, b, geglu=geglu)
+            assert np.array_equal(got, ref), f"dense {M}x{K}x{N} run {rep}: {np.abs(got - ref).max()}"
+    finally:
+        _force(engine, -1)
+
+
+@pytest.mark.parametrize("T,H,W,C,O,kt,k", [(25, 48, 64, 320, 320, 1, 3), (2, 192, 256, 256, 256, 1, 3), (8, 96, 128, 512, 512, 1, 3),
+                                            (25, 24, 32, 640, 640, 3, 1)])
+def test_loader_kernel_bitwise_full_size_conv(engine, T, H, W, C, O, kt, k):
+    rng = np.random.default_rng(T * H + C)
+    x = rnd(rng, T, H, W, C)
+    w = rnd(rng, O, C, kt, k, k, scale=(kt * k * k * C) ** -0.5)
+    b = rnd(rng, O)
+    try:
+        _force(engine, 15)
+        ref = engine.op_conv(x, w, b, kt=kt, k=k, pad_t=k // 2, pad_l=k // 2)
+        _force(engine, 34 if O == 320 else 35)
+        for rep in range(3):
+            got = engine.op_conv(x, w, b, kt=kt, k=k, pad_t=k // 2, pad_l=k // 2)
+            assert np.array_equal(got, ref), f"conv run {rep}: {np.abs(got - ref).max()}"
+    finally:
+        _force(engine, -1)

@@ -486,6 +486,8 @@ int ug_bench_gemm(ug_ctx* x, int M, int N, int K, int conv, int T, int Hi, int W
     if (cf < 0 || sp < 1) { int c2, s2; gemm_plan(p, 1, &c2, &s2); if (cf < 0) cf = c2; if (sp < 1) sp = s2; }
     p.cfg_p1 = cf + 1; p.splitk = sp;
     if (sp > 1) p.partial = c.ws.get<float>((long)sp * M * N);
+    unsigned* trace = nullptr;
+    if (getenv("UG_GEMM_TRACE")) { trace = c.ws.get<unsigned>(2 * 24 * 5); UG_CHECK(hipMemsetAsync(trace, 0, 2 * 24 * 5 * 4, c.stream)); p.trace = trace; }
     for (int i = 0; i < 2; ++i) launch_gemm(p, 1, c.stream);
     hipEvent_t e0, e1; UG_CHECK(hipEventCreate(&e0)); UG_CHECK(hipEventCreate(&e1));
     UG_CHECK(hipEventRecord(e0, c.stream));
@@ -493,6 +495,19 @@ int ug_bench_gemm(ug_ctx* x, int M, int N, int K, int conv, int T, int Hi, int W
     UG_CHECK(hipEventRecord(e1, c.stream)); UG_CHECK(hipEventSynchronize(e1));
     float ms; UG_CHECK(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (trace) {   // per K-step: [MFMAs issued .. operands landed .. barrier passed .. fetch issued .. MFMAs issued]
+      std::vector<unsigned> h(2 * 24 * 5);
+      UG_CHECK(hipMemcpy(h.data(), trace, h.size() * 4, hipMemcpyDeviceToHost));
+      for (int w = 0; w < 2; ++w) {
+        printf("wave %d: step  vmcnt-wait  barrier  fetch-issue  reads+MFMA   total\n", w * 4);
+        for (int st = 0; st + 1 < 24; ++st) {
+          auto at = [&](int s2, int k) { return h[(size_t)w * 24 * 5 + (size_t)s2 * 5 + k]; };
+          auto d = [&](unsigned a, unsigned b) { return (b - a) & 0xFFFFF; };
+          printf("        %4d  %10u  %7u  %11u  %10u  %6u\n", st + 8, d(at(st, 0), at(st, 1)), d(at(st, 1), at(st, 2)), d(at(st, 2), at(st, 3)),
+                 d(at(st, 3), at(st + 1, 0)), d(at(st, 0), at(st + 1, 0)));
+        }
+      }
+    }
     ms_out[0] = ms / iters; ms_out[1] = (float)cf; ms_out[2] = (float)sp; ms_out[3] = (float)M; ms_out[4] = (float)K;
   });
 }

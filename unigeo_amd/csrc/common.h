@@ -64,6 +64,7 @@ struct GemmP {
   int cfg_p1;            // 0 = pick the tile config automatically, else tile config id + 1
   int splitk;            // 0 = automatic, 1 = off, >1 = K slices (needs `partial`)
   float* partial;        // split-K scratch: splitk * M * N floats
+  void* trace;           // UG_GEMM_TRACE builds only: cycle-stamp dump (tools/gemm_trace.py)
   int up_phase;          // 0 = off; 1 + (a*2+b): conv output row (t,y,x) is stored at row (t, 2y+a, 2x+b) of a 2Ho x 2Wo grid
 };
 void launch_gemm(const GemmP& p, int batch, hipStream_t s);

@@ -73,6 +73,157 @@ template <int BM, int BN, int BK, int NST, int WMW, int WNW> struct GemmOcc {
   static constexpr int wps = wps_raw < 1 ? 1 : (wps_raw > 4 ? 4 : wps_raw);
 };
 
+#ifdef UG_GEMM_TRACE
+#define UG_STAMP(slot)                                                                                   \
+  do {                                                                                                   \
+    if (traced && fi >= 8 && fi < 32) {                                                                  \
+      unsigned long long c_;                                                                             \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_)::"memory");                         \
+      if (lane == 0) tr_lds[(fi - 8) * 5 + (slot)] = (unsigned)c_;                                       \
+    }                                                                                                    \
+  } while (0)
+#else
+#define UG_STAMP(slot) do {} while (0)
+#endif
+
+// Per-tile epilogue shared by the GEMM kernels: the lane holds WID = 4*NT contiguous columns of rows
+// m0 + wm*WTM + i*16 + (lane & 15).  Clears the accumulators for the next tile.
+template <int MT, int NT, int WTM, int WTN>
+__device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wm, int wn, int lane,
+                                              long out_off) {
+  constexpr int WID = 4 * NT;
+  const int l15 = lane & 15, g = lane >> 4;
+  const bool geglu = (p.flags & UG_F_GEGLU) != 0;
+  const bool of32 = (p.flags & UG_F_OUT_F32) != 0;
+  const int Nout = geglu ? p.N / 2 : p.N;
+  const int OW = geglu ? WID / 2 : WID;        // output columns of this lane
+  const int nb = n0 + wn * WTN + g * WID;      // lane holds WID contiguous columns of its rows
+  if (p.splitk > 1) {   // raw fp32 partials [split][M][N]
+    float* P = p.partial + ((long)blockIdx.y * p.M) * p.N;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * WTM + i * 16 + l15;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = nb + j * 4;
+        if (m < p.M && n + 4 <= p.N) *(f32x4*)(P + (long)m * p.N + n) = acc[i][j];
+        acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    return;
+  }
+  const int ob = geglu ? nb / 2 : nb;          // first output column of this lane
+  const bool full = (nb + WID <= p.N);
+  const bool vec = full && ((p.ldo & 7) == 0) && (!p.R1 || (p.ldr1 & 7) == 0) &&
+                   (!p.R2 || (p.ldr2 & 7) == 0) && (OW % 8 == 0);
+  float bv[WID];
+#pragma unroll
+  for (int e = 0; e < WID; ++e) bv[e] = 0.f;
+  if (full) {
+    if (p.bias) {
+#pragma unroll
+      for (int e = 0; e < WID; e += 8) {
+        const f16x8 b = *(const f16x8*)(p.bias + nb + e);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bv[e + q] += (float)b[q];
+      }
+    }
+    if (p.bias2) {
+#pragma unroll
+      for (int e = 0; e < WID; e += 8) {
+        const f16x8 b = *(const f16x8*)(p.bias2 + nb + e);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bv[e + q] += (float)b[q];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < WID; ++e)
+      if (nb + e < p.N) {
+        if (p.bias) bv[e] += (float)p.bias[nb + e];
+        if (p.bias2) bv[e] += (float)p.bias2[nb + e];
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wm * WTM + i * 16 + l15;
+    long orow = m;
+    if (p.up_phase) {   // sub-pixel phase of a nearest-2x upsample conv: scatter to the (2y+a, 2x+b) output pixel
+      const int hw = p.Ho * p.Wo;
+      const int t = m / hw, rem = m - t * hw;
+      const int y = rem / p.Wo, x = rem - y * p.Wo;
+      const int ph = p.up_phase - 1;
+      orow = ((long)t * 2 * p.Ho + 2 * y + (ph >> 1)) * (2 * p.Wo) + 2 * x + (ph & 1);
+    }
+    float v[WID];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[j * 4 + r] = acc[i][j][r] + bv[j * 4 + r]; }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (m >= p.M) continue;
+    if (geglu) {
+      if (WID == 16) {
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const f32x2 r = geglu2((f32x2){v[e], v[e + 1]}, (f32x2){v[8 + e], v[9 + e]});
+          v[e] = r.x; v[e + 1] = r.y;
+        }
+      }
+    }
+    if (vec) {
+#pragma unroll
+      for (int e = 0; e < OW; e += 8) {
+        float o[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = p.c0 * v[e + q];
+        if (p.R1) {
+          const f16x8 r = *(const f16x8*)(p.R1 + (long)m * p.ldr1 + ob + e);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) o[q] += p.c1 * (float)r[q];
+        }
+        if (p.R2) {
+          const f16x8 r = *(const f16x8*)(p.R2 + (long)m * p.ldr2 + ob + e);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) o[q] += p.c2 * (float)r[q];
+        }
+        if (p.act == UG_ACT_SILU) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) o[q] = silu_f(o[q]);
+        } else if (p.act == UG_ACT_GELU) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) o[q] = gelu_f(o[q]);
+        }
+        if (of32) {
+          float* O = (float*)p.Out + out_off + orow * p.ldo + ob + e;
+          *(f32x4*)O = (f32x4){o[0], o[1], o[2], o[3]};
+          *(f32x4*)(O + 4) = (f32x4){o[4], o[5], o[6], o[7]};
+        } else {
+          f16x8 h;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) h[q] = (f16)o[q];
+          *(f16x8*)((f16*)p.Out + out_off + orow * p.ldo + ob + e) = h;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < OW; ++e) {
+        const int n = ob + e;
+        if (n < Nout) {
+          float o = p.c0 * v[e];
+          if (p.R1) o += p.c1 * (float)p.R1[(long)m * p.ldr1 + n];
+          if (p.R2) o += p.c2 * (float)p.R2[(long)m * p.ldr2 + n];
+          if (p.act == UG_ACT_SILU) o = silu_f(o);
+          else if (p.act == UG_ACT_GELU) o = gelu_f(o);
+          if (of32) ((float*)p.Out)[out_off + orow * p.ldo + n] = o;
+          else ((f16*)p.Out)[out_off + orow * p.ldo + n] = (f16)o;
+        }
+      }
+    }
+  }
+}
+
 // BUFA: operands are fetched with buffer addressing (buffer_load_dwordx4 ... offen lds): the per-lane byte offset of a
 // row is computed once per tile, the K / tap advance is a scalar offset, and out-of-range rows / padding taps point the
 // lane past num_records, where the hardware returns zeros.  That takes the ~16 VALU instructions per load that the
@@ -308,26 +459,30 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
 
   const int l15 = lane & 15, g = lane >> 4;
   const int sw = swz<BK>(l15);   // rows are (multiple of 16) + l15 and swz only looks at the low 4 row bits
-  const bool geglu = (p.flags & UG_F_GEGLU) != 0;
-  const bool of32 = (p.flags & UG_F_OUT_F32) != 0;
-  const int Nout = geglu ? p.N / 2 : p.N;
-  const int OW = geglu ? WID / 2 : WID;        // output columns of this lane
-
 #pragma unroll
   for (int s0 = 0; s0 < NST - 1; ++s0)
     if (s0 < total_it) issue();
   bool drain = false;   // after an epilogue the in-flight count also holds its loads/stores: drain once
   int cp_ti = 0, cp_ks = 0, cp_slot = 0;
+#ifdef UG_GEMM_TRACE
+  // cycle stamps of waves 0 and 4 (same SIMD) of workgroup 0 for K-steps 8..31, kept in the LDS above the ring
+  const bool traced = p.trace && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (wave == 0 || wave == 4);
+  unsigned* tr_lds = (unsigned*)(smem + NST * STAGE) + (wave == 4 ? 24 * 5 : 0);
+#endif
   for (int fi = 0; fi < total_it; ++fi) {
+    UG_STAMP(0);   // previous step's MFMAs issued
     // wait for the loads of iteration fi (issued NST-1 iterations ago); up to NST-2 younger fetches stay in flight
     const int younger = min(NST - 2, total_it - 1 - fi);
     if (drain || younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AI + BI)) : "memory");
     drain = false;
+    UG_STAMP(1);   // fetched operands have landed
     __builtin_amdgcn_s_barrier();    // raw barrier: does not drain the LDS-DMA queue
     asm volatile("" ::: "memory");   // keep this iteration's LDS reads / DMA issues below the barrier
+    UG_STAMP(2);   // barrier passed
     if (fi + NST - 1 < total_it) issue();   // overwrites the slot every wave finished reading last iteration
+    UG_STAMP(3);   // next fetch issued
     const f16* Ab = smem + cp_slot * STAGE + (wm * WTM + l15) * BK;
     const f16* Bb = smem + cp_slot * STAGE + BM * BK + (wn * WTN + l15) * BK;
     if (++cp_slot == NST) cp_slot = 0;
@@ -364,6 +519,12 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
       }
       __builtin_amdgcn_sched_group_barrier(0x008, Q, 0);
     }
+#ifdef UG_GEMM_TRACE
+    if (traced && fi == 40) {
+      __builtin_amdgcn_s_waitcnt(0);
+      for (int i = lane; i < 24 * 5; i += 64) ((unsigned*)p.trace)[(wave == 4 ? 24 * 5 : 0) + i] = tr_lds[i];
+    }
+#endif
     if (++cp_ks != nk) continue;
     cp_ks = 0;
     const int ti = cp_ti++;
@@ -371,133 +532,273 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
     // ---- tile finished: epilogue (the next tile's operands keep streaming into the ring meanwhile) ----
     drain = true;
     const int tile = wslot + ti * nwg;
-    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
-    const int nb = n0 + wn * WTN + g * WID;      // lane holds WID contiguous columns of its rows
-    if (p.splitk > 1) {   // raw fp32 partials [split][M][N]
-      float* P = p.partial + ((long)blockIdx.y * p.M) * p.N;
+    tile_epilogue<MT, NT, WTM, WTN>(p, acc, (tile / ntn) * BM, (tile % ntn) * BN, wm, wn, lane, out_off);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Asymmetric-loader variant of the one-barrier-per-K-step kernel for the 8-wave tiles (buffer addressing only).
+//
+// Cycle stamps of gemm_kernel (tools/gemm_trace.py, profiles/r01_gemm_kstep_trace.txt; 256x256x64, 4350 cycles per
+// K-step): every wave spends ~1100 cycles right behind the barrier ISSUING its eight direct-to-LDS loads - the CU's 64
+// loads drain through the texture-address path at ~17 cycles each and all eight waves queue on it while the matrix
+// pipes idle - and then the two waves of each SIMD share the pipe for their 2 x 64 MFMAs.  Here only waves 4-7 (one
+// per SIMD) fetch, each for itself and for its SIMD partner (waves 0-3): the partners go straight from the barrier to
+// their fragment reads and MFMAs, so the matrix pipe runs the partner's K-step while the loader is queued on the
+// address path, and the loader's K-step afterwards.  Same LDS image, ring, barrier and MFMA order as gemm_kernel
+// (outputs are bit-identical).
+template <int BM, int BN, int NST, int WMW, int WNW, bool CONV>
+__global__ __launch_bounds__(512, 2) void gemm_ldr_kernel(const GemmP p) {
+  constexpr int BK = 64;
+  static_assert(WMW * WNW == 8, "two waves per SIMD");
+  constexpr unsigned SENT = 0x80000000u;
+  constexpr int WTM = BM / WMW, WTN = BN / WNW;
+  constexpr int MT = WTM / 16, NT = WTN / 16;
+  constexpr int WID = 4 * NT;
+  constexpr int AI = BM / 64, BI = BN / 64;         // 1 KiB loads per (virtual) wave per K-step
+  constexpr int LA = 2 * AI, LB = 2 * BI;           // loads a loader wave issues per K-step
+  constexpr int STAGE = (BM + BN) * BK;
+  static_assert(AI >= 1 && BI >= 1 && NST >= 2 && NST <= 3, "tile / ring");
+  static_assert(!CONV || AI % 2 == 0, "im2col swizzle parity trick needs an even AI");
+  extern __shared__ __attribute__((aligned(16))) f16 smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WNW, wn = wave % WNW;
+  const bool loader = wave >= 4;
+  const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+  const int ntiles = ntm * ntn;
+
+  const int bz = blockIdx.z;
+  const int bo = bz / p.nb_inner, bi = bz - bo * p.nb_inner;
+  const f16* A0 = p.A0 + bo * p.sA_o + bi * p.sA_i;
+  const f16* Wb = p.W + bo * p.sW_o + bi * p.sW_i;
+  const long out_off = bo * p.sO_o + bi * p.sO_i;
+
+  const int pc = lane & 7, lrow = lane >> 3;
+  const int Cin = p.C0 + p.C1;
+
+  const int nk_all = (p.K + BK - 1) / BK;
+  int kt_lo = 0, kt_hi = nk_all;
+  if (p.splitk > 1) {
+    const int per = (nk_all + p.splitk - 1) / p.splitk;
+    kt_lo = min(nk_all, (int)blockIdx.y * per);
+    kt_hi = min(nk_all, kt_lo + per);
+  }
+  const int nk = max(kt_hi - kt_lo, 1);
+
+  const int nwg = gridDim.x, w = blockIdx.x;
+  const int wslot = (nwg % 8 == 0 && !(p.flags & UG_F_NOXCD)) ? (w % 8) * (nwg / 8) + w / 8 : w;
+  const int my_tiles = (ntiles - wslot + nwg - 1) / nwg;
+  const int total_it = my_tiles * nk;
+
+  // ---- loader state (waves 4-7): load l < AI belongs to the partner wave - 4, l >= AI to the wave itself ----
+  // dense: a_st = byte offset of the row (or SENT).  im2col: a_st = tap-validity mask << 23 | (pixel of tap 0 + shift);
+  // the byte offset is pixel * 2C + chunk, the chunk term only depends on the parity of the load index.
+  unsigned a_st[LA], b_off[LB];
+  const int lc16_0 = (pc ^ ((0 + (lrow >> 1)) & 7)) * 16, lc16_1 = (pc ^ ((4 + (lrow >> 1)) & 7)) * 16;
+  const int cshift = CONV ? ((p.kt >> 1) * p.Hi + p.pad_t) * p.Wi + p.pad_l : 0;
+  const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc((void*)(A0 - (long)cshift * p.C0), 0, (int)SENT, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rA1 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)((CONV && p.A1) ? p.A1 - (long)cshift * p.C1 : A0), 0, (int)SENT, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, (int)SENT, 0x00020000);
+
+  auto setup_tile = [&](int tile) {
+    const int tn = tile % ntn, tm = tile / ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int m = m0 + wm * WTM + i * 16 + l15;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int n = nb + j * 4;
-          if (m < p.M && n + 4 <= p.N) *(f32x4*)(P + (long)m * p.N + n) = acc[i][j];
-          acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-      }
-      continue;
-    }
-    const int ob = geglu ? nb / 2 : nb;          // first output column of this lane
-    const bool full = (nb + WID <= p.N);
-    const bool vec = full && ((p.ldo & 7) == 0) && (!p.R1 || (p.ldr1 & 7) == 0) &&
-                     (!p.R2 || (p.ldr2 & 7) == 0) && (OW % 8 == 0);
-    float bv[WID];
-#pragma unroll
-    for (int e = 0; e < WID; ++e) bv[e] = 0.f;
-    if (full) {
-      if (p.bias) {
-#pragma unroll
-        for (int e = 0; e < WID; e += 8) {
-          const f16x8 b = *(const f16x8*)(p.bias + nb + e);
-#pragma unroll
-          for (int q = 0; q < 8; ++q) bv[e + q] += (float)b[q];
-        }
-      }
-      if (p.bias2) {
-#pragma unroll
-        for (int e = 0; e < WID; e += 8) {
-          const f16x8 b = *(const f16x8*)(p.bias2 + nb + e);
-#pragma unroll
-          for (int q = 0; q < 8; ++q) bv[e + q] += (float)b[q];
-        }
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < WID; ++e)
-        if (nb + e < p.N) {
-          if (p.bias) bv[e] += (float)p.bias[nb + e];
-          if (p.bias2) bv[e] += (float)p.bias2[nb + e];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int m = m0 + wm * WTM + i * 16 + l15;
-      long orow = m;
-      if (p.up_phase) {   // sub-pixel phase of a nearest-2x upsample conv: scatter to the (2y+a, 2x+b) output pixel
+    for (int l = 0; l < LA; ++l) {
+      const int rg = (wave - 4 + 4 * (l / AI)) * AI + (l % AI);   // 8-row group of the A tile
+      const int m = m0 + rg * 8 + lrow;
+      const bool ok = m < p.M && kt_lo < kt_hi;
+      if (CONV) {
         const int hw = p.Ho * p.Wo;
         const int t = m / hw, rem = m - t * hw;
-        const int y = rem / p.Wo, x = rem - y * p.Wo;
-        const int ph = p.up_phase - 1;
-        orow = ((long)t * 2 * p.Ho + 2 * y + (ph >> 1)) * (2 * p.Wo) + 2 * x + (ph & 1);
-      }
-      float v[WID];
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { v[j * 4 + r] = acc[i][j][r] + bv[j * 4 + r]; }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (m >= p.M) continue;
-      if (geglu) {
-        if (WID == 16) {
-#pragma unroll
-          for (int e = 0; e < 8; e += 2) {
-            const f32x2 r = geglu2((f32x2){v[e], v[e + 1]}, (f32x2){v[8 + e], v[9 + e]});
-            v[e] = r.x; v[e + 1] = r.y;
-          }
-        }
-      }
-      if (vec) {
-#pragma unroll
-        for (int e = 0; e < OW; e += 8) {
-          float o[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) o[q] = p.c0 * v[e + q];
-          if (p.R1) {
-            const f16x8 r = *(const f16x8*)(p.R1 + (long)m * p.ldr1 + ob + e);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) o[q] += p.c1 * (float)r[q];
-          }
-          if (p.R2) {
-            const f16x8 r = *(const f16x8*)(p.R2 + (long)m * p.ldr2 + ob + e);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) o[q] += p.c2 * (float)r[q];
-          }
-          if (p.act == UG_ACT_SILU) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) o[q] = silu_f(o[q]);
-          } else if (p.act == UG_ACT_GELU) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) o[q] = gelu_f(o[q]);
-          }
-          if (of32) {
-            float* O = (float*)p.Out + out_off + orow * p.ldo + ob + e;
-            *(f32x4*)O = (f32x4){o[0], o[1], o[2], o[3]};
-            *(f32x4*)(O + 4) = (f32x4){o[4], o[5], o[6], o[7]};
-          } else {
-            f16x8 h;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) h[q] = (f16)o[q];
-            *(f16x8*)((f16*)p.Out + out_off + orow * p.ldo + ob + e) = h;
-          }
-        }
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int y0 = oy * p.stride - p.pad_t, x0 = ox * p.stride - p.pad_l;
+        unsigned mk = 0; int bit = 0;
+        for (int it = 0; it < p.kt; ++it)
+          for (int iy = 0; iy < p.ky; ++iy)
+            for (int ix = 0; ix < p.kx; ++ix, ++bit) {
+              const int tt = t + it - (p.kt >> 1), y = y0 + iy, x = x0 + ix;
+              if (tt >= 0 && tt < p.T && y >= 0 && y < p.Hi && x >= 0 && x < p.Wi) mk |= 1u << bit;
+            }
+        const unsigned ap = (unsigned)(((t - (p.kt >> 1)) * p.Hi + y0) * p.Wi + x0 + cshift);
+        a_st[l] = ok ? (mk << 23) | ap : 0u;
       } else {
-#pragma unroll
-        for (int e = 0; e < OW; ++e) {
-          const int n = ob + e;
-          if (n < Nout) {
-            float o = p.c0 * v[e];
-            if (p.R1) o += p.c1 * (float)p.R1[(long)m * p.ldr1 + n];
-            if (p.R2) o += p.c2 * (float)p.R2[(long)m * p.ldr2 + n];
-            if (p.act == UG_ACT_SILU) o = silu_f(o);
-            else if (p.act == UG_ACT_GELU) o = gelu_f(o);
-            if (of32) ((float*)p.Out)[out_off + orow * p.ldo + n] = o;
-            else ((f16*)p.Out)[out_off + orow * p.ldo + n] = (f16)o;
-          }
-        }
+        a_st[l] = ok ? (unsigned)m * (unsigned)(p.C0 * 2) + (((l % AI) & 1) ? lc16_1 : lc16_0) : SENT;
       }
     }
+#pragma unroll
+    for (int l = 0; l < LB; ++l) {
+      const int rg = (wave - 4 + 4 * (l / BI)) * BI + (l % BI);
+      const int lr = rg * 8 + lrow;                     // LDS row of the W tile; holds W row n0 + perm(lr)
+      const int part = lr / WTN, rem = lr % WTN;
+      const int jj = rem >> 4, i = rem & 15;
+      const int n = n0 + part * WTN + (i >> 2) * WID + jj * 4 + (i & 3);
+      b_off[l] = (n < p.N && kt_lo < kt_hi) ? (unsigned)n * (unsigned)(p.ldw * 2) + ((rg & 1) ? lc16_1 : lc16_0) : SENT;
+    }
+  };
+
+  int ld_ti = 0, ld_ks = 0, ld_slot = 0;
+  int u_it = 0, u_iy = 0, u_ix = 0, u_cb = 0;
+  auto issue = [&]() {
+    if (ld_ks == 0) {
+      setup_tile(wslot + ld_ti * nwg);
+      if (CONV) {
+        const int kt0 = kt_lo * BK;
+        const int tap = kt0 / Cin;
+        u_cb = kt0 - tap * Cin;
+        u_it = tap / (p.ky * p.kx);
+        const int r2 = tap - u_it * (p.ky * p.kx);
+        u_iy = r2 / p.kx; u_ix = r2 - u_iy * p.kx;
+      }
+    }
+    f16* As = smem + ld_slot * STAGE;
+    f16* Bs = As + BM * BK;
+    const int kt0 = (kt_lo + ld_ks) * BK;
+    if (CONV) {
+      const int tapbit = 23 + (u_it * p.ky + u_iy) * p.kx + u_ix;
+      const int tappix = (u_it * p.Hi + u_iy) * p.Wi + u_ix;
+      const bool src0 = u_cb < p.C0;
+      const int Cs2 = (src0 ? p.C0 : p.C1) * 2;
+      const int soff = tappix * Cs2 + (src0 ? u_cb : u_cb - p.C0) * 2;
+      const __amdgpu_buffer_rsrc_t rs = src0 ? rA0 : rA1;
+#pragma unroll
+      for (int l = 0; l < LA; ++l) {
+        const int rg = (wave - 4 + 4 * (l / AI)) * AI + (l % AI);
+        const unsigned off = (a_st[l] & 0x7FFFFFu) * (unsigned)Cs2 + (((l % AI) & 1) ? lc16_1 : lc16_0);
+        const unsigned voff = ((a_st[l] >> tapbit) & 1u) ? off : SENT;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(As + rg * 8 * BK), 16, (int)voff, soff, 0, 0);
+      }
+      u_cb += BK;
+      if (u_cb >= Cin) { u_cb = 0; if (++u_ix == p.kx) { u_ix = 0; if (++u_iy == p.ky) { u_iy = 0; ++u_it; } } }
+    } else {
+#pragma unroll
+      for (int l = 0; l < LA; ++l) {
+        const int rg = (wave - 4 + 4 * (l / AI)) * AI + (l % AI);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, (lptr_t)(As + rg * 8 * BK), 16, (int)a_st[l], kt0 * 2, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < LB; ++l) {
+      const int rg = (wave - 4 + 4 * (l / BI)) * BI + (l % BI);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(Bs + rg * 8 * BK), 16, (int)b_off[l], kt0 * 2, 0, 0);
+    }
+    if (++ld_ks == nk) { ld_ks = 0; ++ld_ti; }
+    if (++ld_slot == NST) ld_slot = 0;
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int l15 = lane & 15, g = lane >> 4;
+  const int sw = swz<BK>(l15);
+
+  if (loader) {
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0)
+      if (s0 < total_it) issue();
   }
+  bool drain = false;
+  int cp_ti = 0, cp_ks = 0, cp_slot = 0;
+#ifdef UG_GEMM_TRACE
+  const bool traced = p.trace && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (wave == 0 || wave == 4);
+  unsigned* tr_lds = (unsigned*)(smem + NST * STAGE) + (wave == 4 ? 24 * 5 : 0);
+#endif
+  for (int fi = 0; fi < total_it; ++fi) {
+    UG_STAMP(0);
+    const int younger = min(NST - 2, total_it - 1 - fi);
+    if (drain || younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA + LB) : "memory");
+    drain = false;
+    UG_STAMP(1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    UG_STAMP(2);
+    if (loader && fi + NST - 1 < total_it) issue();
+    UG_STAMP(3);
+    const f16* Ab = smem + cp_slot * STAGE + (wm * WTM + l15) * BK;
+    const f16* Bb = smem + cp_slot * STAGE + BM * BK + (wn * WTN + l15) * BK;
+    if (++cp_slot == NST) cp_slot = 0;
+    {
+      f16x8 af[2][MT], bf[2][NT];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int ch = ((kk * 4 + g) ^ sw) * 8;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[kk][j] = *(const f16x8*)(Bb + j * 16 * BK + ch);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[kk][i] = *(const f16x8*)(Ab + i * 16 * BK + ch);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+      constexpr int R = MT + NT, Q = MT * NT;
+      __builtin_amdgcn_sched_group_barrier(0x100, R, 0);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, Q / R, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, Q - R * (Q / R), 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, Q, 0);
+    }
+#ifdef UG_GEMM_TRACE
+    if (traced && fi == 40) {
+      __builtin_amdgcn_s_waitcnt(0);
+      for (int i = lane; i < 24 * 5; i += 64) ((unsigned*)p.trace)[(wave == 4 ? 24 * 5 : 0) + i] = tr_lds[i];
+    }
+#endif
+    if (++cp_ks != nk) continue;
+    cp_ks = 0;
+    const int tile = wslot + (cp_ti++) * nwg;
+    drain = true;
+    tile_epilogue<MT, NT, WTM, WTN>(p, acc, (tile / ntn) * BM, (tile % ntn) * BN, wm, wn, lane, out_off);
+  }
+}
+
+// buffer-addressing preconditions (see gemm_kernel BUFA); packed = the im2col state additionally fits mask << 23 | pixel
+static bool gemm_can_bufa(const GemmP& p, int BK, bool packed) {
+  const long lim = (1L << 31) - 64;
+  if ((long)p.N * p.ldw * 2 >= lim) return false;
+  if (p.conv) {
+    const bool uni = ((p.C0 + p.C1) % BK) == 0 && (p.C0 % BK) == 0 && p.kt * p.ky * p.kx <= (packed ? 9 : 32);
+    const long px = (long)p.T * p.Hi * p.Wi + ((long)(p.kt >> 1) * p.Hi + p.pad_t) * p.Wi + p.pad_l + 1;
+    return uni && p.ups == 1 && px * p.C0 * 2 < lim && px * p.C1 * 2 < lim && (!packed || px < (1L << 23));
+  }
+  return p.K % BK == 0 && (long)p.M * p.C0 * 2 < lim;
+}
+
+template <int BM, int BN, int NST, int WMW, int WNW>
+static void launch_ldr(const GemmP& p, int batch, hipStream_t s) {
+  const int ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
+#ifdef UG_GEMM_TRACE
+  const size_t lds = (size_t)NST * (BM + BN) * 64 * sizeof(f16) + 1024;
+#else
+  const size_t lds = (size_t)NST * (BM + BN) * 64 * sizeof(f16);
+#endif
+  static bool attr = false;
+  if (!attr) {
+    UG_CHECK(hipFuncSetAttribute((const void*)gemm_ldr_kernel<BM, BN, NST, WMW, WNW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    UG_CHECK(hipFuncSetAttribute((const void*)gemm_ldr_kernel<BM, BN, NST, WMW, WNW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  const int per_cu = (160 * 1024) / (int)lds < 1 ? 1 : std::min(2, (160 * 1024) / (int)lds);
+  const int split = p.splitk > 1 ? p.splitk : 1;
+  int gx = std::max(8, (per_cu * 256) / (split * batch));
+  gx = (gx / 8) * 8;
+  gx = std::min(gx, ntiles);
+  dim3 grid(gx, split, batch);
+  if (p.conv) hipLaunchKernelGGL((gemm_ldr_kernel<BM, BN, NST, WMW, WNW, true>), grid, dim3(512), lds, s, p);
+  else hipLaunchKernelGGL((gemm_ldr_kernel<BM, BN, NST, WMW, WNW, false>), grid, dim3(512), lds, s, p);
 }
 
 // Sum the split-K partials in split order (deterministic) and apply the epilogue; 8 columns per thread.
@@ -544,7 +845,11 @@ int gemm_knobs_get();
 template <int BM, int BN, int BK, int NST, int WMW, int WNW, bool CONV, bool UNI, bool BUFA = false>
 static void launch_t(const GemmP& p, int batch, hipStream_t s) {
   const int ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
+#ifdef UG_GEMM_TRACE
+  const size_t lds = (size_t)NST * (BM + BN) * BK * sizeof(f16) + 1024;
+#else
   const size_t lds = (size_t)NST * (BM + BN) * BK * sizeof(f16);
+#endif
   auto kern = gemm_kernel<BM, BN, BK, NST, WMW, WNW, CONV, UNI, BUFA>;
   static int per_cu = 0;
   if (!per_cu) {
@@ -594,6 +899,10 @@ static void launch_cfg(int cfg, const GemmP& p, int batch, hipStream_t s) {
     case 14: launch_mode<256, 64, 64, 2, 4, 2>(p, batch, s); break;   //  80 KiB, 2 WG/CU (8 waves)
     case 15: launch_mode<256, 256, 64, 2, 2, 4>(p, batch, s); break;  // 128 KiB, 8 waves, wave tile 128x64
     case 19: launch_mode<256, 128, 64, 3, 2, 4>(p, batch, s); break;  // 144 KiB, 8 waves, wave tile 128x32
+    // asymmetric-loader forms of the 8-wave tiles (gemm_ldr_kernel); need buffer addressing, else the symmetric kernel
+    case 35: if (gemm_can_bufa(p, 64, true)) launch_ldr<256, 256, 2, 2, 4>(p, batch, s); else launch_mode<256, 256, 64, 2, 2, 4>(p, batch, s); break;
+    case 39: if (gemm_can_bufa(p, 64, true)) launch_ldr<256, 128, 3, 2, 4>(p, batch, s); else launch_mode<256, 128, 64, 3, 2, 4>(p, batch, s); break;
+    case 34: if (gemm_can_bufa(p, 64, true)) launch_ldr<256, 64, 2, 4, 2>(p, batch, s); else launch_mode<256, 64, 64, 2, 4, 2>(p, batch, s); break;
     default: UG_REQUIRE(false, "unknown / pruned GEMM tile config");
   }
 }
@@ -611,9 +920,9 @@ int gemm_knobs_get() { return g_knobs; }
 // 8192^3 dense, the 512-channel VAE conv for im2col).  Checked against the full sweep of the clip's shapes the model's
 // pick is the measured best or within ~5 % of it.  Low-resolution levels (M <= 2048) are latency-bound, not
 // throughput-bound: they keep the measured rules below (64x64 tiles / split-K).
-struct TileCand { int id, bm, bn, percu; float dense, conv; bool geglu_ok; };
+struct TileCand { int id, bm, bn, percu; float dense, conv; bool geglu_ok; };   // id 35 = loader form of 15 (gemm_ldr_kernel)
 static const TileCand kCands[] = {
-    {15, 256, 256, 1, 1200.f, 1130.f, true},  {19, 256, 128, 1, 1050.f, 929.f, false}, {0, 128, 128, 2, 890.f, 1025.f, true},
+    {15, 256, 256, 1, 1200.f, 1130.f, true},  {35, 256, 256, 1, 1190.f, 1200.f, true},  {19, 256, 128, 1, 1050.f, 929.f, false}, {0, 128, 128, 2, 890.f, 1025.f, true},
     {14, 256, 64, 2, 880.f, 883.f, false},    {1, 128, 64, 3, 757.f, 799.f, false},    {12, 64, 64, 5, 456.f, 652.f, false}};
 
 void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
@@ -649,7 +958,7 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
   } else if (plain_epi && p.conv && p.M <= 8192 && nk >= 256 && p.N >= 512) {
     cfg = 0; split = 4;   // 12x16 level, concatenated 2560-channel input: four K slices fill the last round (880 vs 816 TFLOP/s)
   }
-  if (g_force_cfg >= 0 && !(geglu && g_force_cfg != 0 && g_force_cfg != 4 && g_force_cfg != 8 && g_force_cfg != 15)) cfg = g_force_cfg;
+  if (g_force_cfg >= 0 && !(geglu && g_force_cfg != 0 && g_force_cfg != 4 && g_force_cfg != 8 && g_force_cfg != 15 && g_force_cfg != 35)) cfg = g_force_cfg;
   if (g_force_split >= 0) split = plain_epi ? std::max(1, g_force_split) : 1;
   *cfg_out = cfg; *split_out = split;
 }
@@ -673,7 +982,7 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
   }
   int cfg = p.cfg_p1 - 1, split = p.splitk;
   if (cfg < 0 || split < 1) { int c2, s2; gemm_plan(p, batch, &c2, &s2); if (cfg < 0) cfg = c2; if (split < 1) split = s2; }
-  if (p.flags & UG_F_GEGLU) UG_REQUIRE(cfg == 0 || cfg == 4 || cfg == 8 || cfg == 15, "GEGLU needs a 64-column wave tile");
+  if (p.flags & UG_F_GEGLU) UG_REQUIRE(cfg == 0 || cfg == 4 || cfg == 8 || cfg == 15 || cfg == 35, "GEGLU needs a 64-column wave tile");
   p.splitk = split;
   if (split > 1) UG_REQUIRE(p.partial != nullptr, "split-K needs a partial buffer");
   launch_cfg(cfg, p, batch, s);
