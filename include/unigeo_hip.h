@@ -130,6 +130,8 @@ int ug_op_euler_step(ug_ctx* ctx, const float* v, float* latents_inout, long n, 
 
 /* Tuning aids (not on the product path): GEMM / implicit-conv microbenchmark on device-resident random data,
  * and an override of the tile/split-K heuristic (-1 = heuristic). ms_out: [ms per launch, cfg, split, M, K]. */
+/* GroupNorm launch-scheme A/B (mode: launch_groupnorm in kernels/norm.hip); tuning aid, no reference counterpart. */
+int ug_bench_groupnorm(ug_ctx* ctx, int C0, int C1, int T, int HW, int temporal, int mode, int iters, float* us_out);
 int ug_bench_gemm(ug_ctx* ctx, int M, int N, int K, int conv, int T, int Hi, int Wi, int C0, int C1, int kt, int k,
                   int stride, int ups, int cfg, int split, int iters, float* ms_out);
 int ug_tune_force(int cfg, int split);

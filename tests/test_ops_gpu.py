@@ -277,6 +277,29 @@ def test_groupnorm_full_size(engine):
         assert_close(got, F.silu(y).numpy(), TOL, f"groupnorm T{T} HW{HW} C{C} temporal={temporal}")
 
 
+@pytest.mark.parametrize("T,HW,C0,C1,temporal", [
+    (25, 3072, 320, 0, False), (25, 3072, 320, 0, True), (25, 768, 640, 0, False), (25, 768, 640, 640, True),
+    (25, 192, 1280, 0, False), (25, 192, 1280, 1280, False), (25, 48, 1280, 1280, True), (25, 48, 1280, 0, False),
+    (3, 100, 64, 32, False), (64, 12, 32, 0, True)])
+def test_groupnorm_unet_shapes_two_sources(engine, T, HW, C0, C1, temporal):
+    """Every (level, concat, pooled) GroupNorm shape of the UNet, both launch schemes' territory; repeated results must be
+    bit-identical (fixed reduction order)."""
+    rng = np.random.default_rng(T * HW + C0 + C1)
+    C = C0 + C1
+    x0 = rnd(rng, T, HW, C0) + 0.25
+    x1 = rnd(rng, T, HW, C1) * 2 - 0.5 if C1 else None
+    gm, bt = rnd(rng, C) + 1, rnd(rng, C)
+    outs = [engine.op_groupnorm(x0, 32, 1e-6, gm, bt, temporal=temporal, silu=True, x1=x1) for _ in range(4)]
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
+    xt = t(np.concatenate([x0, x1], -1) if C1 else x0)
+    if temporal:
+        y = F.group_norm(xt.permute(2, 0, 1)[None], 32, t(gm), t(bt), 1e-6)[0].permute(1, 2, 0)
+    else:
+        y = F.group_norm(xt.permute(0, 2, 1), 32, t(gm), t(bt), 1e-6).permute(0, 2, 1)
+    assert_close(outs[0], F.silu(y).numpy(), TOL, f"groupnorm T{T} HW{HW} C{C0}+{C1} temporal={temporal}")
+
+
 def test_flash_attention_full_size_properties(engine):
     """S = 3072 (UNet level 0): spot-check rows against fp64 softmax attention, and the size-independent property that
     attention is invariant to a permutation of the keys/values."""

@@ -22,7 +22,7 @@ EXPORTS = [
     "ug_eval_depth", "ug_eval_normal", "ug_clip_embed", "ug_vae_encode", "ug_vae_decode", "ug_unet_forward", "ug_normals_from_depth",
     "ug_op_linear", "ug_op_conv", "ug_op_groupnorm", "ug_op_layernorm", "ug_op_flash_attn",
     "ug_op_temporal_attn", "ug_op_attention_generic", "ug_op_euler_step",
-    "ug_profile_begin", "ug_profile_begin_shapes", "ug_profile_end", "ug_bench_gemm", "ug_tune_force",
+    "ug_profile_begin", "ug_profile_begin_shapes", "ug_profile_end", "ug_bench_gemm", "ug_bench_groupnorm", "ug_tune_force",
 ]
 
 
@@ -95,6 +95,7 @@ def load_library():
     lib.ug_op_euler_step.argtypes = [vp, vp, vp, C.c_long, C.c_float, C.c_float]
     lib.ug_profile_begin.argtypes = [vp]
     lib.ug_bench_gemm.argtypes = [vp] + [ip] * 16 + [vp]
+    lib.ug_bench_groupnorm.argtypes = [vp, ip, ip, ip, ip, ip, ip, ip, vp]
     lib.ug_tune_force.argtypes = [ip, ip]
     lib.ug_profile_begin_shapes.argtypes = [vp]
     lib.ug_profile_end.restype = C.c_char_p
@@ -335,6 +336,11 @@ class Engine:
                                         cv.get("ups", 1), cfg, split, iters, _ptr(out)))
         Mr, Kr = float(out[3]), float(out[4])
         return float(out[0]), 2.0 * Mr * N * Kr / (out[0] * 1e-3) / 1e12, int(out[1]), int(out[2])
+
+    def bench_groupnorm(self, C0, C1, T, HW, temporal, mode, iters=20):
+        out = np.zeros(1, np.float32)
+        self._ck(self.lib.ug_bench_groupnorm(self.ctx, C0, C1, T, HW, int(temporal), mode, iters, _ptr(out)))
+        return float(out[0])
 
     # ---- profiling
     def profile_begin(self, shapes=False):

@@ -397,6 +397,29 @@ int ug_op_groupnorm(ug_ctx* x, const float* x0, int C0, const float* x1, int C1,
   });
 }
 
+int ug_bench_groupnorm(ug_ctx* x, int C0, int C1, int T, int HW, int temporal, int mode, int iters, float* us_out) {
+  UG_TRY(x, {
+    Ctx& c = x->c; Scope sc(c);
+    const int C = C0 + C1; const long M = (long)T * HW;
+    GroupNormP p; memset(&p, 0, sizeof(p));
+    f16* a0 = c.ws.get<f16>(M * C0); f16* a1 = C1 ? c.ws.get<f16>(M * C1) : nullptr;
+    launch_fill_random(a0, M * C0, 1, c.stream); if (C1) launch_fill_random(a1, M * C1, 2, c.stream);
+    f16* gm = c.ws.get<f16>(C); f16* bt = c.ws.get<f16>(C);
+    launch_fill_random(gm, C, 3, c.stream); launch_fill_random(bt, C, 4, c.stream);
+    p.X0 = a0; p.X1 = a1; p.C0 = C0; p.C1 = C1; p.T = T; p.HW = HW; p.G = 32; p.eps = 1e-5f; p.temporal = temporal; p.silu = 1;
+    p.gamma = gm; p.beta = bt; p.Y = c.ws.get<f16>(M * C); p.mode = mode;
+    p.ws = c.ws.get<float>((long)groupnorm_ws_floats(T, HW, C, 32));
+    for (int i = 0; i < 3; ++i) launch_groupnorm(p, c.stream);
+    hipEvent_t e0, e1; UG_CHECK(hipEventCreate(&e0)); UG_CHECK(hipEventCreate(&e1));
+    UG_CHECK(hipEventRecord(e0, c.stream));
+    for (int i = 0; i < iters; ++i) launch_groupnorm(p, c.stream);
+    UG_CHECK(hipEventRecord(e1, c.stream)); UG_CHECK(hipEventSynchronize(e1));
+    float ms; UG_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    us_out[0] = ms * 1000.f / iters;
+  });
+}
+
 int ug_op_layernorm(ug_ctx* x, const float* xin, int M, int C, float eps, const float* gamma, const float* beta,
                     const float* addvec, int rows_per_vec, float* out, float* xout) {
   UG_TRY(x, {

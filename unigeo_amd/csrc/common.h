@@ -82,6 +82,7 @@ struct GroupNormP {
   const f16* gamma; const f16* beta;
   f16* Y;                 // [T*HW, C0+C1]
   float* ws;              // >= T * G * 2 * nchunk floats (+ T*G*2 for mean/rstd)
+  int mode;               // 0 = automatic; 1 / 2 force a launch scheme (launch_groupnorm)
 };
 void launch_groupnorm(const GroupNormP& p, hipStream_t s);
 size_t groupnorm_ws_floats(int T, int HW, int C, int G);

@@ -12,6 +12,8 @@
 // The input may be the virtual channel-concat of two tensors (UNet up-block skip connections)
 // - group boundaries straddle the two sources there, so the concat cannot be factored out.
 #include "../common.h"
+#include <algorithm>
+#include <cstdlib>
 
 #define GN_THREADS 256
 #define GN_MAXV 3  // vectors per thread => C <= 3*256*8
@@ -33,11 +35,10 @@ __device__ __forceinline__ f16x8 gn_load(const GroupNormP& p, long m, int c) {
   return (c < p.C0) ? *(const f16x8*)(p.X0 + m * p.C0 + c) : *(const f16x8*)(p.X1 + m * p.C1 + (c - p.C0));
 }
 
-__global__ __launch_bounds__(GN_THREADS) void gn_stats(const GroupNormP p, int nchunk, int rows_per_chunk) {
-  extern __shared__ float red[];  // [rpi][C][2]
+// phase 1 of GroupNorm for workgroup (chunk, t): per-group sum / sum-of-squares partials of the chunk's rows -> p.ws
+__device__ __forceinline__ void gn_stats_body(const GroupNormP& p, int t, int chunk, int nchunk, int rows_per_chunk, float* red) {
   const int C = p.C0 + p.C1;
   const GnGeom gg = gn_geom(C);
-  const int t = blockIdx.y, chunk = blockIdx.x;
   const int tid = threadIdx.x;
   const int rsub = tid / gg.tpr, v0 = tid - rsub * gg.tpr;
   const bool active = rsub < gg.rpi;
@@ -105,6 +106,11 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats(const GroupNormP p, int n
   }
 }
 
+__global__ __launch_bounds__(GN_THREADS) void gn_stats(const GroupNormP p, int nchunk, int rows_per_chunk) {
+  extern __shared__ float red[];  // [rpi][C][2]
+  gn_stats_body(p, blockIdx.y, blockIdx.x, nchunk, rows_per_chunk, red);
+}
+
 __global__ __launch_bounds__(1024) void gn_finalize(const GroupNormP p, int nchunk, float* ab) {
   // grid (T), NT = 256 or 1024 threads: NT/G threads cooperate on one group's chunk partials (fp64, fixed order)
   __shared__ double sa[1024], sb[1024];
@@ -149,10 +155,11 @@ __global__ __launch_bounds__(1024) void gn_finalize(const GroupNormP p, int nchu
   }
 }
 
-__global__ __launch_bounds__(GN_THREADS) void gn_apply(const GroupNormP p, int rows_per_chunk, const float* ab) {
+// phase 3 for workgroup (chunk, t): y = silu(x * a[c] + b[c]); coef(c, a, b) supplies the per-channel scale / shift
+template <typename F>
+__device__ __forceinline__ void gn_apply_body(const GroupNormP& p, int t, int chunk, int rows_per_chunk, F coef) {
   const int C = p.C0 + p.C1;
   const GnGeom gg = gn_geom(C);
-  const int t = blockIdx.y, chunk = blockIdx.x;
   const int tid = threadIdx.x;
   const int rsub = tid / gg.tpr, v0 = tid - rsub * gg.tpr;
   if (rsub >= gg.rpi) return;
@@ -165,8 +172,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply(const GroupNormP p, int r
     if (k < gg.vpt && v < gg.nvec) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        a[k][e] = ab[((long)t * C + v * 8 + e) * 2 + 0];
-        b[k][e] = ab[((long)t * C + v * 8 + e) * 2 + 1];
+        coef(v * 8 + e, a[k][e], b[k][e]);
       }
     }
   }
@@ -220,6 +226,11 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply(const GroupNormP p, int r
       }
     }
   }
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_apply(const GroupNormP p, int rows_per_chunk, const float* ab) {
+  const int C = p.C0 + p.C1, t = blockIdx.y;
+  gn_apply_body(p, t, blockIdx.x, rows_per_chunk, [&](int c, float& a, float& b) { a = ab[((long)t * C + c) * 2 + 0]; b = ab[((long)t * C + c) * 2 + 1]; });
 }
 
 // rows per chunk: enough workgroups (T * nchunk >= ~1024) to fill 256 CUs several times over, but at
@@ -296,29 +307,36 @@ size_t groupnorm_ws_floats(int T, int HW, int C, int G) {
   return (size_t)T * nchunk * G * 2 + (size_t)T * C * 2;
 }
 
+// Launch scheme (p.mode 0 = pick, 1 / 2 force; tools/bench_groupnorm.py, profiles/r01_groupnorm_variants.txt):
+//   1: gn_stats / gn_finalize / gn_apply   2: gn_small, one workgroup per (group, frame) - wins on the low-resolution levels,
+//      loses when a row contributes < 64 B to a group and there are many rows (T25 x HW768 x C640: 47 vs 28 us).
+// Also measured and removed: apply with an in-block finalize (2 launches; +3.5 us of serial latency per workgroup, no
+// gain) and a single launch with a device-scope barrier (agent-scope release/acquire flushes and invalidates the whole
+// L2: 162 ms of GroupNorm per clip; with the partials as coherent atomics instead: 140 ms; three launches: 113 ms).
 void launch_groupnorm(const GroupNormP& p, hipStream_t s) {
   const int C = p.C0 + p.C1;
   UG_REQUIRE(p.C0 % 8 == 0 && p.C1 % 8 == 0, "GroupNorm channels must be multiples of 8");
   UG_REQUIRE(C % p.G == 0 && p.G <= 256 && 256 % p.G == 0, "GroupNorm group count must divide 256");
   UG_REQUIRE(C <= GN_MAXV * GN_THREADS * 8, "GroupNorm too many channels");
-  {
-    const int cpg = C / p.G;
-    const long slab = (long)p.HW * cpg * (p.temporal ? p.T : 1);
-    if (!p.temporal && cpg % 4 == 0 && p.C0 % 4 == 0 && p.gamma && p.beta && slab <= 16384) {
-      hipLaunchKernelGGL(gn_small, dim3(p.G, p.temporal ? 1 : p.T), dim3(256), 0, s, p);
-      UG_CHECK(hipGetLastError());
-      return;
-    }
+  const int cpg = C / p.G;
+  const long slab = (long)p.HW * cpg * (p.temporal ? p.T : 1);
+  const bool small_ok = !p.temporal && cpg % 4 == 0 && p.C0 % 4 == 0 && p.gamma && p.beta;
+  int mode = p.mode;
+  if (mode == 0) mode = (small_ok && slab <= 16384 && (p.HW <= 256 || cpg >= 32)) ? 2 : 1;
+  if (mode == 2 && !small_ok) mode = 1;
+  if (mode == 2) {
+    hipLaunchKernelGGL(gn_small, dim3(p.G, p.T), dim3(256), 0, s, p);
+  } else {
+    int nchunk, rpc;
+    gn_chunks2(p.T, p.HW, C, nchunk, rpc);
+    const GnGeom gg = gn_geom(C);
+    const size_t lds = (size_t)gg.rpi * C * 2 * sizeof(float);
+    float* ab = p.ws + (size_t)p.T * nchunk * p.G * 2;
+    hipLaunchKernelGGL(gn_stats, dim3(nchunk, p.T), dim3(GN_THREADS), lds, s, p, nchunk, rpc);
+    const int fin_threads = ((p.temporal ? p.T : 1) * nchunk > 64) ? 1024 : 256;
+    hipLaunchKernelGGL(gn_finalize, dim3(p.T), dim3(fin_threads), 0, s, p, nchunk, ab);
+    hipLaunchKernelGGL(gn_apply, dim3(nchunk, p.T), dim3(GN_THREADS), 0, s, p, rpc, (const float*)ab);
   }
-  int nchunk, rpc;
-  gn_chunks2(p.T, p.HW, C, nchunk, rpc);
-  const GnGeom gg = gn_geom(C);
-  float* ab = p.ws + (size_t)p.T * nchunk * p.G * 2;
-  const size_t lds = (size_t)gg.rpi * C * 2 * sizeof(float);
-  hipLaunchKernelGGL(gn_stats, dim3(nchunk, p.T), dim3(GN_THREADS), lds, s, p, nchunk, rpc);
-  const int fin_threads = ((p.temporal ? p.T : 1) * nchunk > 64) ? 1024 : 256;
-  hipLaunchKernelGGL(gn_finalize, dim3(p.T), dim3(fin_threads), 0, s, p, nchunk, ab);
-  hipLaunchKernelGGL(gn_apply, dim3(nchunk, p.T), dim3(GN_THREADS), 0, s, p, rpc, (const float*)ab);
   UG_CHECK(hipGetLastError());
 }
 
