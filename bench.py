@@ -148,13 +148,13 @@ def main():
             ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
             res["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_TFLOPS_F16, 4), "traffic": None,
-                               "kernel": "gemm_kernel<BN,CONV,UNI> (all linear / 3x3 / 1x1 / temporal-conv / attention GEMM launches)",
+                               "kernel": "gemm_kernel<...> + gemm_ldr_kernel<...> (all linear / 3x3 / 1x1 / temporal-conv / attention GEMM launches)",
                                "launches": g_calls, "avg_launch_us": round(g_ms * 1000.0 / max(g_calls, 1), 2),
                                "algorithmic_tflop": round(g_fl / 1e12, 2)}
             try:   # HBM traffic of the same kernel family from the committed PMC passes (tools/pmc_traffic.sh)
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_gemm.json")))
                 res["roofline"]["traffic"] = round(pm["hbm_bytes_per_launch"])
-                res["roofline"]["traffic_note"] = ("bytes per gemm_kernel launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes "
+                res["roofline"]["traffic_note"] = ("bytes per GEMM-family launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes "
                                                    "on a 3-step clip (profiles/r01_pmc_traffic_gemm.json), FETCH doubled per the gfx950 note")
             except Exception:
                 pass

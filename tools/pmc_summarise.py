@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Sum a PMC counter over the gemm_kernel dispatches of a rocprofv3 counter_collection CSV."""
+"""Sum a PMC counter over the GEMM-family dispatches (gemm_kernel, gemm_ldr_kernel) of a rocprofv3 counter_collection CSV and,
+given the FETCH_SIZE and WRITE_SIZE pass directories, write the per-launch traffic summary bench.py reads."""
 import csv, glob, json, os, sys
 out = {}
 for d in sys.argv[1:]:
@@ -7,8 +8,19 @@ for d in sys.argv[1:]:
     tot, n, name = 0.0, 0, None
     for f in files:
         for row in csv.DictReader(open(f)):
-            if "gemm_kernel" in row.get("Kernel_Name", ""):
+            if "gemm_kernel" in row.get("Kernel_Name", "") or "gemm_ldr_kernel" in row.get("Kernel_Name", ""):
                 tot += float(row["Counter_Value"]); n += 1; name = row["Counter_Name"]
     out[name or os.path.basename(d)] = {"sum": tot, "dispatch_rows": n}
 print(json.dumps(out))
 json.dump(out, open("gpurun_out/pmc_summary.json", "w"))
+
+if "FETCH_SIZE" in out and "WRITE_SIZE" in out and out["FETCH_SIZE"]["dispatch_rows"]:
+    n = out["FETCH_SIZE"]["dispatch_rows"]
+    rd = out["FETCH_SIZE"]["sum"] * 1024 * 2 / n          # counters are in KB; FETCH doubled (gfx950 note)
+    wr = out["WRITE_SIZE"]["sum"] * 1024 / out["WRITE_SIZE"]["dispatch_rows"]
+    json.dump({"workload": "tools/one_clip.py 3 (25x384x512 clip, 3 Euler steps, CLIP + VAE enc/dec), GEMM-family dispatches only",
+               "dispatches": n, "FETCH_SIZE_sum_KB": out["FETCH_SIZE"]["sum"], "WRITE_SIZE_sum_KB": out["WRITE_SIZE"]["sum"],
+               "correction": "FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B on wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported",
+               "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
+               "collection": "two separate passes: rocprofv3 --pmc FETCH_SIZE / rocprofv3 --pmc WRITE_SIZE (tools/pmc_traffic.sh); fabric-side counters include Infinity-Cache hits"},
+              open("gpurun_out/pmc_traffic_gemm.json", "w"), indent=1)
