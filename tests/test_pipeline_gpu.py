@@ -131,6 +131,28 @@ def test_full_size_invariants():
         pipe.engine.close()
 
 
+def test_larger_clip_geometry():
+    """BASELINE configs[4] geometry in fp16 (50 frames at 576 x 768, 1 Euler step): T = 50 temporal attention / pooled GroupNorm,
+    S = 6912 spatial attention, > 2^31-element-free 32-bit buffer offsets, 12 GiB of activations - finite, in range, reproducible."""
+    from unigeo_amd.pipeline import DepthCrafterPipelineHIP, make_noise
+    from unigeo_amd.synthetic import synthetic_clip
+    from unigeo_amd.model.depthcrafter import DepthCrafter
+    pipe = DepthCrafterPipelineHIP.from_random(seed=42, workspace_bytes=64 << 30)
+    try:
+        T, H, W = 50, 576, 768
+        clip = synthetic_clip(T, H, W)
+        frames = DepthCrafter.prepare_input(None, clip)
+        nl, na = make_noise(T, H, W, 0)
+        r1 = pipe(frames, num_inference_steps=1, window_size=T, noise_latents=nl, noise_aug=na)
+        d1 = r1.depth.copy()
+        assert d1.shape == (T, H, W) and np.isfinite(d1).all() and d1.min() >= 1 / 1.1 - 1e-5 and d1.max() <= 10 + 1e-4
+        assert d1.std() > 1e-3                      # not a constant map
+        r2 = pipe(frames, num_inference_steps=1, window_size=T, noise_latents=nl, noise_aug=na)
+        assert np.array_equal(r2.depth, d1)
+    finally:
+        pipe.engine.close()
+
+
 def test_device_metrics_match_reference_goldens(engine):
     """G5: the reference's own depth_evaluation(align_with_lstsq=True, custom_mask) / normal_evaluation outputs."""
     res, (s, t_) = engine.eval_depth(G["g5_gt_d"], G["g5_mask"], pred=G["g5_pred_d"])
