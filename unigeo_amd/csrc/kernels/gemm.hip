@@ -938,6 +938,9 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
     if (c.id == 19 && p.conv && p.K <= 512) sc *= 1.15f;   // its 3-stage ring hides the short K loop's fill (temporal convs, K = 3C); in-situ it loses on dense K = 320
     if (sc > best) { best = sc; cfg = c.id; }
   }
+  // in-situ exception (tools/insitu_cfg_sweep.py): the level-0 down-projection (M = 76800, N = 320, K = 1280) re-reads its 197 MB
+  // A operand once per 64-column tile; the 256x128 3-stage tile needs 3 instead of 5 passes (122 vs 131 us)
+  if (!p.conv && !geglu && p.M >= 50000 && p.N > 256 && p.N <= 384 && p.K >= 1024) cfg = 4;
   int split = 1;
   const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * batch;
   const int nk = cdiv(p.K, 64);
