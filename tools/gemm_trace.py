@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-K-step cycle stamps (s_memtime) of two co-resident waves of the GEMM kernel.  Needs the instrumented build:
-   hipcc -DUG_GEMM_TRACE on kernels/gemm.hip + capi.hip -> unigeo_amd/csrc/build/trace/libunigeo_trace.so
+   make -C unigeo_amd/csrc trace  ->  unigeo_amd/csrc/build/trace/libunigeo_trace.so
 usage: gemm_trace.py <problem> <cfg>"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
