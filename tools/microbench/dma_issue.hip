@@ -3,6 +3,9 @@
 //   mode 0: a fresh M0 (LDS base) for every load                  - what the GEMM kernels do
 //   mode 1: one M0 per 4 loads, the LDS row selected by the instruction's immediate offset (compensated in soffset)
 //   mode 2: plain global_load_dwordx4 into VGPRs (no LDS), for reference
+// build: hipcc --offload-arch=gfx950 -O3 dma_issue.hip -o dma_issue (the binary is not tracked).  Result on MI355X with L2-resident
+// data: a CU moves 64 KiB per ~1410 cycles with 8 waves issuing (46 B/clk of the 64 B/clk path while all 256 CUs hit L2 at once),
+// M0 rewrites do not matter, plain global loads cost the same - the fetch of a 256x256x64 K-step is >= 1024 cycles of that path.
 // Prints cycles per load seen by wave 0 (s_memtime around the issue loop, and around issue + vmcnt(0)).
 #include <hip/hip_runtime.h>
 #include <cstdio>
