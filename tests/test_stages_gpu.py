@@ -149,3 +149,25 @@ def test_pipeline_edge_cases(tiny, T, H, W, steps, chunk):
     got = res.frames[0]
     assert got.shape == ref.shape and np.isfinite(got).all()
     assert np.abs(got - ref).max() < 3e-2, np.abs(got - ref).max()
+
+
+def test_frame_count_limits(tiny):
+    """Maximum clip length (64 frames: one temporal-attention tile) runs and matches the oracle; one more frame, an empty clip and
+    a ragged noise tensor are refused with a message instead of being truncated or padded."""
+    from oracle.pipeline import run_pipeline
+    from unigeo_amd.pipeline import make_noise
+    T, H, W = 64, 64, 64
+    rng = np.random.default_rng(64)
+    frames = rng.uniform(0, 1, (T, H, W, 3)).astype(np.float32)
+    nl, na = make_noise(T, H, W, seed=1)
+    res = tiny["pipe"](frames, num_inference_steps=1, window_size=T, noise_latents=nl, noise_aug=na)
+    ref = run_pipeline(tiny["unet"], tiny["vae"], tiny["clip"], frames, torch.from_numpy(nl), torch.from_numpy(na), steps=1, chunk=8)
+    assert np.abs(res.frames[0] - ref).max() < 3e-2
+    big = rng.uniform(0, 1, (65, H, W, 3)).astype(np.float32)
+    nl2, na2 = make_noise(65, H, W, seed=1)
+    with pytest.raises((RuntimeError, ValueError, NotImplementedError)):
+        tiny["pipe"](big, num_inference_steps=1, window_size=65, noise_latents=nl2, noise_aug=na2)
+    with pytest.raises((RuntimeError, ValueError)):
+        tiny["pipe"](frames[:0], num_inference_steps=1, window_size=1, noise_latents=nl[:, :0], noise_aug=na[:0])
+    with pytest.raises((RuntimeError, ValueError)):
+        tiny["pipe"](frames, num_inference_steps=1, window_size=T, noise_latents=nl[:, :10], noise_aug=na)
