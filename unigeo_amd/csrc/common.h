@@ -41,7 +41,7 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //   optional nearest-2x upsample of the source, optional channel concat of two sources).
 // ---------------------------------------------------------------------------------------
 enum { UG_ACT_NONE = 0, UG_ACT_SILU = 1, UG_ACT_GELU = 2 };
-enum { UG_F_GEGLU = 1, UG_F_OUT_F32 = 2, UG_F_NOXCD = 4 };
+enum { UG_F_GEGLU = 1, UG_F_OUT_F32 = 2, UG_F_NOXCD = 4, UG_F_PRIO = 8 /* tuning knob: static priority for the younger half of an 8-wave workgroup */ };
 
 struct GemmP {
   const f16* A0; const f16* A1;

@@ -251,6 +251,9 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WNW, wn = wave % WNW;
+  // static priority for the second-dispatched half of an 8-wave workgroup (it loses every arbitration against its SIMD partner
+  // otherwise): +0..6 % on the 256x256 tile, neutral-to-negative on the others (knob 16 forces it there for A/B runs)
+  if (NWAVE == 8 && wave >= 4 && ((BM == 256 && BN == 256) || (p.flags & UG_F_PRIO))) __builtin_amdgcn_s_setprio(1);
   const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
   const int ntiles = ntm * ntn;
 
@@ -969,6 +972,7 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
 void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
   GemmP p = p0;
   if (g_knobs & 2) p.flags |= UG_F_NOXCD;
+  if (g_knobs & 16) p.flags |= UG_F_PRIO;
   UG_REQUIRE(p.K % 8 == 0, "GEMM K must be a multiple of 8");
   UG_REQUIRE(p.ldw % 8 == 0, "GEMM ldw must be a multiple of 8");
   UG_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "empty GEMM");
