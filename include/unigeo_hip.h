@@ -86,6 +86,11 @@ int ug_bind_clip(ug_ctx* ctx, const ug_clip_config* cfg);
 int ug_dc_set_inputs(ug_ctx* ctx, const float* frames_thwc, int T, int H, int W, const float* noise_latents,
                      const float* noise_aug, const float* intrinsics_t33);
 int ug_dc_run(ug_ctx* ctx, int steps, int decode_chunk, int with_normals);
+/* Long-video mode of the pipeline call (`window_size` / `overlap` of model/depthcrafter.py:87-88, which the reference pins to
+ * len(frames) / 25, i.e. OFF): latent sliding windows of `window` (<= 64) frames with `overlap` re-noised + cross-faded frames,
+ * restated from upstream DepthCrafter's published pipeline (UNPINNED).  window == 0 or >= T is ug_dc_run.  The first `window`
+ * frames of the noise passed to ug_dc_set_inputs are the window noise (rotated by `overlap` frames per window, as upstream). */
+int ug_dc_run_windows(ug_ctx* ctx, int steps, int decode_chunk, int with_normals, int window, int overlap);
 int ug_dc_get_outputs(ug_ctx* ctx, float* frames_out, float* depth_out, float* normals_out);
 /* Device addresses of the resident outputs (valid until the next ug_dc_set_inputs): lets the caller hand
  * them to RCCL (torch.distributed) for the cross-GPU gather without a host round trip. */

@@ -30,9 +30,15 @@ def prepare_input(images):
 
 @torch.no_grad()
 def run_pipeline(unet, vae, clip, frames_thwc, noise_latents, noise_aug, steps,
-                 chunk=8, dtype=torch.float32, vae_encode_dtype=None, return_stages=False):
+                 chunk=8, dtype=torch.float32, vae_encode_dtype=None, return_stages=False, window=None, overlap=0):
     """frames_thwc np/tensor [T,H,W,3] f32 in [0,1]; noise_latents [1,T,4,h,w];
-    noise_aug [T,3,H,W] -> np [T,H,W,3] f32 in [0,1]."""
+    noise_aug [T,3,H,W] -> np [T,H,W,3] f32 in [0,1].
+
+    window < T switches on the long-video mode of upstream DepthCrafter's pipeline (latent sliding windows; the reference
+    never does: model/depthcrafter.py:87-88 passes window_size = len(frames)).  Restated from the published pipeline -
+    PARITY UNPINNED: windows advance by window - overlap; a window after the first starts its first `overlap` frames from the
+    previous result re-noised to sigma_0; the window's unit noise is the previous one rotated by `overlap` frames; the overlap is
+    cross-faded with linspace(0, 1, overlap) into the running result.  The first `window` frames of noise_latents are the noise."""
     st = {}
     video = torch.as_tensor(frames_thwc).permute(0, 3, 1, 2).to(dtype)
     video = video * 2.0 - 1.0
@@ -55,14 +61,38 @@ def run_pipeline(unet, vae, clip, frames_thwc, noise_latents, noise_aug, steps,
     added = torch.tensor([ADDED_TIME_IDS], dtype=dtype)
     sch = EulerKarrasVPred()
     ts = sch.set_timesteps(steps)
-    latents = noise_latents.to(dtype) * sch.init_noise_sigma
-    for i, t in enumerate(ts):
-        x = sch.scale_model_input(latents, i)
-        x = torch.cat([x, cond], dim=2)
-        v = unet(x, t, emb, added)
-        if i == 0:
-            st["unet_out0"] = v
-        latents = sch.step(v, i, latents)
+    if window is None or window >= T:
+        latents = noise_latents.to(dtype) * sch.init_noise_sigma
+        for i, t in enumerate(ts):
+            x = sch.scale_model_input(latents, i)
+            x = torch.cat([x, cond], dim=2)
+            v = unet(x, t, emb, added)
+            if i == 0:
+                st["unet_out0"] = v
+            latents = sch.step(v, i, latents)
+    else:
+        stride = window - overlap
+        latents_init = noise_latents[:, :window].to(dtype) * sch.init_noise_sigma
+        weights = torch.linspace(0, 1, overlap, dtype=dtype).view(1, overlap, 1, 1, 1) if overlap > 0 else None
+        latents_all, idx_start = None, 0
+        while idx_start < T - overlap:
+            idx_end = min(idx_start + window, T)
+            cur = latents_init[:, :idx_end - idx_start].clone()
+            latents_init = torch.cat([latents_init[:, -overlap:], latents_init[:, :stride]], dim=1) if overlap > 0 else latents_init
+            cond_w, emb_w = cond[:, idx_start:idx_end], emb[:, idx_start:idx_end]
+            for i, t in enumerate(ts):
+                if latents_all is not None and i == 0 and overlap > 0:
+                    cur[:, :overlap] = latents_all[:, -overlap:] + cur[:, :overlap] / sch.init_noise_sigma * sch.sigmas[i]
+                x = torch.cat([sch.scale_model_input(cur, i), cond_w], dim=2)
+                cur = sch.step(unet(x, t, emb_w, added), i, cur)
+            if latents_all is None:
+                latents_all = cur.clone()
+            else:
+                if overlap > 0:
+                    latents_all[:, -overlap:] = cur[:, :overlap] * weights + latents_all[:, -overlap:] * (1 - weights)
+                latents_all = torch.cat([latents_all, cur[:, overlap:]], dim=1)
+            idx_start += stride
+        latents = latents_all
     st["latents"] = latents
     z = latents.flatten(0, 1) / SCALING
     out = []

@@ -18,7 +18,7 @@ EXPORTS = [
     "ug_unet_config_default", "ug_vae_config_default", "ug_clip_config_default",
     "ug_create", "ug_destroy", "ug_last_error", "ug_workspace_peak",
     "ug_load_tensor", "ug_bind_unet", "ug_bind_vae", "ug_bind_clip",
-    "ug_dc_set_inputs", "ug_dc_run", "ug_dc_get_outputs", "ug_dc_device_ptrs",
+    "ug_dc_set_inputs", "ug_dc_run", "ug_dc_run_windows", "ug_dc_get_outputs", "ug_dc_device_ptrs",
     "ug_eval_depth", "ug_eval_normal", "ug_clip_embed", "ug_vae_encode", "ug_vae_decode", "ug_unet_forward", "ug_normals_from_depth",
     "ug_op_linear", "ug_op_conv", "ug_op_groupnorm", "ug_op_layernorm", "ug_op_flash_attn",
     "ug_op_temporal_attn", "ug_op_attention_generic", "ug_op_euler_step",
@@ -76,6 +76,7 @@ def load_library():
     lib.ug_bind_clip.argtypes = [vp, C.POINTER(CLIPConfigC)]
     lib.ug_dc_set_inputs.argtypes = [vp, vp, ip, ip, ip, vp, vp, vp]
     lib.ug_dc_run.argtypes = [vp, ip, ip, ip]
+    lib.ug_dc_run_windows.argtypes = [vp, ip, ip, ip, ip, ip]
     lib.ug_dc_get_outputs.argtypes = [vp, vp, vp, vp]
     lib.ug_dc_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.ug_eval_depth.argtypes = [vp, vp, vp, vp, C.c_long, C.c_float, vp]
@@ -199,8 +200,11 @@ class Engine:
         self._ck(self.lib.ug_dc_set_inputs(self.ctx, _ptr(f), T, H, W, _ptr(nl), _ptr(na), _ptr(k)))
         self._shape = (T, H, W)
 
-    def run(self, steps, decode_chunk=8, with_normals=False):
-        self._ck(self.lib.ug_dc_run(self.ctx, int(steps), int(decode_chunk), int(bool(with_normals))))
+    def run(self, steps, decode_chunk=8, with_normals=False, window=0, overlap=0):
+        if window:
+            self._ck(self.lib.ug_dc_run_windows(self.ctx, int(steps), int(decode_chunk), int(bool(with_normals)), int(window), int(overlap)))
+        else:
+            self._ck(self.lib.ug_dc_run(self.ctx, int(steps), int(decode_chunk), int(bool(with_normals))))
 
     def get_outputs(self, frames=True, depth=True, normals=False):
         T, H, W = self._shape

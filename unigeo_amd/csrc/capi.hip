@@ -118,6 +118,9 @@ int ug_dc_set_inputs(ug_ctx* x, const float* frames, int T, int H, int W, const 
   UG_TRY(x, dc_set_inputs(x->c, frames, T, H, W, nl, na, K));
 }
 int ug_dc_run(ug_ctx* x, int steps, int chunk, int with_normals) { UG_TRY(x, dc_run(x->c, steps, chunk, with_normals)); }
+int ug_dc_run_windows(ug_ctx* x, int steps, int chunk, int with_normals, int window, int overlap) {
+  UG_TRY(x, dc_run(x->c, steps, chunk, with_normals, window, overlap));
+}
 int ug_dc_get_outputs(ug_ctx* x, float* f, float* d, float* n) { UG_TRY(x, dc_get_outputs(x->c, f, d, n)); }
 
 int ug_dc_device_ptrs(ug_ctx* x, void** f, void** d, void** n) {

@@ -155,6 +155,8 @@ void launch_make_unet_input(const f16* lat, const f16* cond, f16* x, long pixels
                             hipStream_t s);   // x[p, 0:4] = lat/sqrt(s^2+1), x[p,4:8] = cond
 void launch_euler_step(const f16* v, f16* lat, long n, float sigma, float sigma_next, hipStream_t s);
 void launch_scale_f16(const f16* in, f16* out, float sc, long n, hipStream_t s);
+void launch_axpby_f16(const f16* x, float a, const f16* y, float b, f16* out, long n, hipStream_t s);
+void launch_crossfade_f16(const f16* cur, f16* all, long frame_elems, int overlap, hipStream_t s);
 void launch_pad_channels(const f16* in, int Cin, f16* out, int Cout, long pixels, hipStream_t s);
 void launch_time_conv_out(const f16* x, const f16* w, const f16* b, float* frames_out, int T,
                           long HW, int Cs, hipStream_t s);  // + (x/2+0.5).clamp(0,1) -> f32 [T,HW,3]

@@ -129,7 +129,7 @@ f16* clip_embed(Ctx& c, const f16* video_m11, int T, int H, int W);       // [T,
 // ---- pipeline ----
 void dc_set_inputs(Ctx& c, const float* frames, int T, int H, int W, const float* noise_lat, const float* noise_aug,
                    const float* K33);
-void dc_run(Ctx& c, int steps, int chunk, int with_normals);
+void dc_run(Ctx& c, int steps, int chunk, int with_normals, int window = 0, int overlap = 0);
 void dc_get_outputs(Ctx& c, float* frames, float* depth, float* normals);
 
 // profiling helpers

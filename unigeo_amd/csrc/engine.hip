@@ -965,7 +965,7 @@ f16* clip_embed(Ctx& c, const f16* video_m11, int T, int H, int W) {
 void dc_set_inputs(Ctx& c, const float* frames, int T, int H, int W, const float* noise_lat, const float* noise_aug,
                    const float* K33) {
   UG_REQUIRE(H % 64 == 0 && W % 64 == 0, "height and width must be multiples of 64 (VAE /8, UNet /8)");
-  UG_REQUIRE(T >= 1 && T <= 64, "1..64 frames per clip");
+  UG_REQUIRE(T >= 1 && T <= 4096, "1..4096 frames (at most 64 per denoising window)");
   if (c.io_ready) { c.ws.release(c.io_mark); c.io_ready = false; }
   c.io_mark = c.ws.mark();
   c.T = T; c.H = H; c.W = W;
@@ -995,10 +995,19 @@ static void karras_sigmas(int n, std::vector<float>& sig, std::vector<float>& ts
   sig[n] = 0.f;
 }
 
-void dc_run(Ctx& c, int steps, int chunk, int with_normals) {
+// window == 0 (or >= T): the reference path, one denoising pass over the whole clip (model/depthcrafter.py:87-88 passes
+// window_size = len(frames)).  0 < window < T: upstream DepthCrafter's long-video mode, restated from the
+// published pipeline - UNPINNED, the reference never takes it: windows of `window` frames advance by window - overlap; a
+// window after the first starts its first `overlap` frames from the previous window's result re-noised to sigma_0
+// (latents_all[-overlap:] + noise * sigma_0), the unit noise of the window is the previous one rotated by `overlap` frames, and the
+// overlap is cross-faded linearly into the running result.  CLIP / VAE conditioning is computed once for all frames.
+void dc_run(Ctx& c, int steps, int chunk, int with_normals, int window, int overlap) {
   UG_REQUIRE(c.io_ready, "ug_dc_set_inputs must be called first");
   UG_REQUIRE(steps >= 1 && chunk >= 1, "steps/chunk");
   const int T = c.T, H = c.H, W = c.W, h = H / 8, w = W / 8;
+  const bool windows = window > 0 && window < T;
+  if (windows) UG_REQUIRE(window <= 64 && overlap >= 0 && overlap < window, "window must be <= 64 frames and overlap < window");
+  else UG_REQUIRE(T <= 64, "more than 64 frames need latent sliding windows (window <= 64)");
   const long px = (long)T * H * W, lp = (long)T * h * w;
   const size_t mk = c.ws.mark();
   // 1. inputs -> fp16, [-1,1], noise augmentation
@@ -1020,17 +1029,58 @@ void dc_run(Ctx& c, int steps, int chunk, int with_normals) {
   std::vector<float> sig, ts;
   karras_sigmas(steps, sig, ts);
   const float sigma0 = sqrtf(sig[0] * sig[0] + 1.f);    // init_noise_sigma, "leading" spacing
-  f16* lat = c.ws.get<f16>(lp * 4);
-  launch_init_latents2(c.d_noise_lat, lat, sigma0, T, (long)h * w, c.stream);
-  unet_prepare(c, T, emb, ts.data(), steps);
-  f16* xin = c.ws.get<f16>(lp * 8);
-  // 5. denoise loop: no host sync inside
-  for (int i = 0; i < steps; ++i) {
-    const size_t m2 = c.ws.mark();
-    launch_make_unet_input(lat, cond, xin, lp, sqrtf(sig[i] * sig[i] + 1.f), c.stream);
-    f16* v = unet_forward(c, xin, T, h, w, i);
-    launch_euler_step(v, lat, lp * 4, sig[i], sig[i + 1], c.stream);
-    c.ws.release(m2);
+  f16* lat = c.ws.get<f16>(lp * 4);      // running result (all frames)
+  if (!windows) {
+    launch_init_latents2(c.d_noise_lat, lat, sigma0, T, (long)h * w, c.stream);
+    unet_prepare(c, T, emb, ts.data(), steps);
+    f16* xin = c.ws.get<f16>(lp * 8);
+    // 5. denoise loop: no host sync inside
+    for (int i = 0; i < steps; ++i) {
+      const size_t m2 = c.ws.mark();
+      launch_make_unet_input(lat, cond, xin, lp, sqrtf(sig[i] * sig[i] + 1.f), c.stream);
+      f16* v = unet_forward(c, xin, T, h, w, i);
+      launch_euler_step(v, lat, lp * 4, sig[i], sig[i + 1], c.stream);
+      c.ws.release(m2);
+    }
+  } else {
+    const long fe = (long)h * w * 4;                     // latent elements per frame
+    const int stride = window - overlap;
+    f16* init = c.ws.get<f16>(fe * window);              // latents_init: unit noise * sigma0 for one window
+    f16* rot = c.ws.get<f16>(fe * window);
+    f16* cur = c.ws.get<f16>(fe * window);
+    f16* xin = c.ws.get<f16>(fe * window * 2);
+    launch_init_latents2(c.d_noise_lat, init, sigma0, window, (long)h * w, c.stream);
+    int n_all = 0;
+    for (int s0 = 0; s0 < T - overlap; s0 += stride) {
+      const int Tw = std::min(window, T - s0);
+      const long lw = fe * Tw;
+      UG_CHECK(hipMemcpyAsync(cur, init, (size_t)lw * 2, hipMemcpyDeviceToDevice, c.stream));
+      // latents_init <- cat(latents_init[-overlap:], latents_init[:stride])
+      if (overlap) UG_CHECK(hipMemcpyAsync(rot, init + fe * (window - overlap), (size_t)fe * overlap * 2, hipMemcpyDeviceToDevice, c.stream));
+      UG_CHECK(hipMemcpyAsync(rot + fe * overlap, init, (size_t)fe * stride * 2, hipMemcpyDeviceToDevice, c.stream));
+      std::swap(init, rot);
+      if (n_all > 0 && overlap)   // first `overlap` frames: previous result + noise at sigma_0 (cur holds noise * sigma0)
+        launch_axpby_f16(lat + fe * (n_all - overlap), 1.f, cur, sig[0] / sigma0, cur, fe * overlap, c.stream);
+      const size_t mw = c.ws.mark();
+      unet_prepare(c, Tw, emb + (long)s0 * c.clip.cfg.proj, ts.data(), steps);
+      for (int i = 0; i < steps; ++i) {
+        const size_t m2 = c.ws.mark();
+        launch_make_unet_input(cur, cond + fe * s0, xin, (long)Tw * h * w, sqrtf(sig[i] * sig[i] + 1.f), c.stream);
+        f16* v = unet_forward(c, xin, Tw, h, w, i);
+        launch_euler_step(v, cur, lw, sig[i], sig[i + 1], c.stream);
+        c.ws.release(m2);
+      }
+      c.ws.release(mw);
+      if (n_all == 0) {
+        UG_CHECK(hipMemcpyAsync(lat, cur, (size_t)lw * 2, hipMemcpyDeviceToDevice, c.stream));
+        n_all = Tw;
+      } else {
+        if (overlap) launch_crossfade_f16(cur, lat + fe * (n_all - overlap), fe, overlap, c.stream);
+        UG_CHECK(hipMemcpyAsync(lat + fe * n_all, cur + fe * overlap, (size_t)fe * (Tw - overlap) * 2, hipMemcpyDeviceToDevice, c.stream));
+        n_all += Tw - overlap;
+      }
+    }
+    UG_REQUIRE(n_all == T, "window bookkeeping");
   }
   // 6. decode in chunks of `chunk` frames (temporal layers only see the chunk, as in the reference)
   f16* z = c.ws.get<f16>(lp * 4);

@@ -299,6 +299,26 @@ void launch_scale_f16(const f16* in, f16* out, float sc, long n, hipStream_t s) 
   hipLaunchKernelGGL(k_scale, gs_grid(n), dim3(256), 0, s, in, out, sc, n);
 }
 
+// out = a * x + b * y (fp16 storage, fp32 arithmetic); latent sliding windows: re-noising of the overlap frames
+__global__ void k_axpby(const f16* x, float a, const f16* y, float b, f16* out, long n) {
+  GS_LOOP(i, n) out[i] = (f16)(a * (float)x[i] + b * (float)y[i]);
+}
+void launch_axpby_f16(const f16* x, float a, const f16* y, float b, f16* out, long n, hipStream_t s) {
+  hipLaunchKernelGGL(k_axpby, gs_grid(n), dim3(256), 0, s, x, a, y, b, out, n);
+}
+// linear cross-fade over `overlap` frames: all[f] = cur[f] * w_f + all[f] * (1 - w_f), w_f = f / (overlap - 1)
+__global__ void k_crossfade(const f16* cur, f16* all, long frame_elems, int overlap) {
+  const long n = frame_elems * overlap;
+  GS_LOOP(i, n) {
+    const int f = (int)(i / frame_elems);
+    const float w = overlap > 1 ? (float)f / (float)(overlap - 1) : 0.f;
+    all[i] = (f16)((float)cur[i] * w + (float)all[i] * (1.f - w));
+  }
+}
+void launch_crossfade_f16(const f16* cur, f16* all, long frame_elems, int overlap, hipStream_t s) {
+  hipLaunchKernelGGL(k_crossfade, gs_grid(frame_elems * overlap), dim3(256), 0, s, cur, all, frame_elems, overlap);
+}
+
 __global__ void k_pad_channels(const f16* in, int Cin, f16* out, int Cout, long pixels) {
   const long n = pixels * Cout;
   GS_LOOP(idx, n) {

@@ -92,9 +92,10 @@ class DepthCrafterPipelineHIP:
             raise ValueError("height and width must be multiples of 64")
         if guidance_scale > 1.0:
             raise NotImplementedError("classifier-free guidance is not on the reference path (guidance_scale=1.0)")
-        if T > window_size:
-            raise NotImplementedError("latent sliding windows (num_frames > window_size) are disabled in the "
-                                      "reference (window_size=len(frames)); SURVEY.md 8f rank 4")
+        if T > window_size and window_size > 64:
+            raise ValueError("a denoising window holds at most 64 frames (temporal attention tile); pass window_size <= 64")
+        if T > window_size and not 0 <= overlap < window_size:
+            raise ValueError("overlap must be in [0, window_size)")
         if abs(noise_aug_strength - 0.02) > 1e-9:
             raise NotImplementedError("noise_aug_strength is fixed at the pipeline default 0.02")
         if output_type != "np":
@@ -104,6 +105,7 @@ class DepthCrafterPipelineHIP:
         chunk = decode_chunk_size or self.decode_chunk_size
         eng = self.engine
         eng.set_inputs(video, noise_latents, noise_aug, intrinsics)
-        eng.run(num_inference_steps, chunk, with_normals=with_normals)
+        # T > window_size: upstream DepthCrafter's latent sliding windows (off on the reference path, which passes window_size = T)
+        eng.run(num_inference_steps, chunk, with_normals=with_normals, window=window_size if T > window_size else 0, overlap=overlap)
         frames, depth, normals = eng.get_outputs(frames=True, depth=True, normals=with_normals)
         return SimpleNamespace(frames=[frames], depth=depth, normals=normals)
