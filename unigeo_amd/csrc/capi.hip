@@ -513,7 +513,7 @@ int ug_bench_gemm(ug_ctx* x, int M, int N, int K, int conv, int T, int Hi, int W
     p.cfg_p1 = cf + 1; p.splitk = sp;
     if (sp > 1) p.partial = c.ws.get<float>((long)sp * M * N);
     unsigned* trace = nullptr;
-    if (getenv("UG_GEMM_TRACE")) { trace = c.ws.get<unsigned>(2 * 24 * 5); UG_CHECK(hipMemsetAsync(trace, 0, 2 * 24 * 5 * 4, c.stream)); p.trace = trace; }
+    if (getenv("UG_GEMM_TRACE")) { trace = c.ws.get<unsigned>(3 * 24 * 5); UG_CHECK(hipMemsetAsync(trace, 0, 3 * 24 * 5 * 4, c.stream)); p.trace = trace; }
     for (int i = 0; i < 2; ++i) launch_gemm(p, 1, c.stream);
     hipEvent_t e0, e1; UG_CHECK(hipEventCreate(&e0)); UG_CHECK(hipEventCreate(&e1));
     UG_CHECK(hipEventRecord(e0, c.stream));
@@ -522,10 +522,12 @@ int ug_bench_gemm(ug_ctx* x, int M, int N, int K, int conv, int T, int Hi, int W
     float ms; UG_CHECK(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (trace) {   // per K-step: [MFMAs issued .. operands landed .. barrier passed .. fetch issued .. MFMAs issued]
-      std::vector<unsigned> h(2 * 24 * 5);
+      std::vector<unsigned> h(3 * 24 * 5);
       UG_CHECK(hipMemcpy(h.data(), trace, h.size() * 4, hipMemcpyDeviceToHost));
-      for (int w = 0; w < 2; ++w) {
-        printf("wave %d: step  vmcnt-wait  barrier  fetch-issue  reads+MFMA   total\n", w * 4);
+      for (int w = 0; w < 3; ++w) {
+        if (w == 2 && h[2 * 24 * 5] == 0) break;   // only the producer / consumer kernel has a third traced wave (a fetch wave)
+        printf("wave %d: step  stamp0->1   1->2   2->3   3->next0   total   (gemm_kernel: vmcnt-wait, barrier, fetch-issue, reads+MFMA;"
+               " gemm_ws consumer: reads+MFMA, epilogue+lgkm, barrier, -; producer: fetch-issue, vmcnt-wait, barrier, -)\n", w * 4);
         for (int st = 0; st + 1 < 24; ++st) {
           auto at = [&](int s2, int k) { return h[(size_t)w * 24 * 5 + (size_t)s2 * 5 + k]; };
           auto d = [&](unsigned a, unsigned b) { return (b - a) & 0xFFFFF; };

@@ -780,6 +780,275 @@ static bool gemm_can_bufa(const GemmP& p, int BK, bool packed) {
   return p.K % BK == 0 && (long)p.M * p.C0 * 2 < lim;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Producer / consumer kernel (256x128x64 tile, three-slot ring, buffer addressing only): 12 waves per workgroup, three
+// per SIMD.  Waves 0-7 only compute (LDS fragment reads + MFMAs + the tile epilogue), waves 8-11 - one per SIMD - only
+// fetch (12 direct-to-LDS loads per K-step each).
+//
+// Why: the K-step traces (profiles/r01_gemm_kstep_trace.txt) show address-path time and matrix time adding up whenever
+// a wave does both jobs - a wave queued on the address path cannot issue its MFMAs - and every re-arrangement of the two
+// jobs inside the same waves (spread loads, 8-phase groups, 4-slot software pipeline) stayed within +-5 %.  The
+// microbenchmark tools/microbench/mfma_vs_dma.hip shows the hardware itself has no such coupling: an MFMA stream keeps its
+// 16.3 cycles per instruction while the SIMD partner issues LDS-DMA loads back to back.  So the fetch gets its own waves.
+// The accumulator of a 256x128 tile is 64 registers per consumer lane, which leaves room for a third wave per SIMD
+// (<= 168 VGPRs each); the fetch waves need ~30.
+//
+// Synchronisation: one s_barrier per K-step for all 12 waves.  In step i the consumers read slot i % 3; the producers
+// issue the fetch of step i+2 into slot (i+2) % 3 (the consumers left it before the previous barrier) and wait until only
+// those 12 loads are in flight (the fetch of step i+1 has landed) before they arrive: the barrier that ends step i both
+// publishes step i+1 and frees slot i % 3.  Only producers ever have loads in flight in the K loop, so the epilogue's
+// global traffic (consumers) needs no drain logic.  LDS image, W row permutation, MFMA chain order and epilogue are those
+// of gemm_kernel: outputs are bit-identical.
+template <int WMW, int WNW, bool CONV>
+__global__ __launch_bounds__(768, 3) void gemm_ws_kernel(const GemmP p) {
+  constexpr int BM = 256, BN = 128, BK = 64, NST = 3;
+  static_assert(WMW * WNW == 8, "eight consumer waves");
+  constexpr unsigned SENT = 0x80000000u;
+  constexpr int WTM = BM / WMW, WTN = BN / WNW;
+  constexpr int MT = WTM / 16, NT = WTN / 16;
+  constexpr int WID = 4 * NT;
+  constexpr int LA = 8, LB = 4;                      // 1 KiB loads per producer wave per K-step (32 A + 16 B pieces / 4 waves)
+  constexpr int STAGE = (BM + BN) * BK;
+  extern __shared__ __attribute__((aligned(16))) f16 smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= 8;
+  const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+  const int ntiles = ntm * ntn;
+
+  const int bz = blockIdx.z;
+  const int bo = bz / p.nb_inner, bi = bz - bo * p.nb_inner;
+  const f16* A0 = p.A0 + bo * p.sA_o + bi * p.sA_i;
+  const f16* Wb = p.W + bo * p.sW_o + bi * p.sW_i;
+  const long out_off = bo * p.sO_o + bi * p.sO_i;
+
+  const int nk_all = (p.K + BK - 1) / BK;
+  int kt_lo = 0, kt_hi = nk_all;
+  if (p.splitk > 1) {
+    const int per = (nk_all + p.splitk - 1) / p.splitk;
+    kt_lo = min(nk_all, (int)blockIdx.y * per);
+    kt_hi = min(nk_all, kt_lo + per);
+  }
+  const int nk = max(kt_hi - kt_lo, 1);
+
+  const int nwg = gridDim.x, w = blockIdx.x;
+  const int wslot = (nwg % 8 == 0 && !(p.flags & UG_F_NOXCD)) ? (w % 8) * (nwg / 8) + w / 8 : w;
+  const int my_tiles = (ntiles - wslot + nwg - 1) / nwg;
+  const int total_it = my_tiles * nk;
+
+  if (producer) {
+    // ================================= fetch waves =================================
+    const int pw = wave - 8;                          // 0..3
+    const int pc = lane & 7, lrow = lane >> 3;
+    const int Cin = p.C0 + p.C1;
+    const int lc16_0 = (pc ^ ((0 + (lrow >> 1)) & 7)) * 16, lc16_1 = (pc ^ ((4 + (lrow >> 1)) & 7)) * 16;
+    const int cshift = CONV ? ((p.kt >> 1) * p.Hi + p.pad_t) * p.Wi + p.pad_l : 0;
+    const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc((void*)(A0 - (long)cshift * p.C0), 0, (int)SENT, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA1 =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((CONV && p.A1) ? p.A1 - (long)cshift * p.C1 : A0), 0, (int)SENT, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, (int)SENT, 0x00020000);
+    // dense: a_st = byte offset of the row (or SENT); im2col: tap-validity mask << 23 | (pixel of tap 0 + shift)
+    unsigned a_st[LA], b_off[LB];
+    int ld_ti = 0, ld_ks = 0, ld_slot = 0;
+    int u_it = 0, u_iy = 0, u_ix = 0, u_cb = 0;
+    auto issue = [&]() {
+      if (ld_ks == 0) {
+        const int tile = wslot + ld_ti * nwg;
+        const int tn = tile % ntn, tm = tile / ntn;
+        const int m0 = tm * BM, n0 = tn * BN;
+#pragma unroll
+        for (int l = 0; l < LA; ++l) {
+          const int rg = pw * LA + l;                   // 8-row group of the A tile
+          const int m = m0 + rg * 8 + lrow;
+          const bool ok = m < p.M && kt_lo < kt_hi;
+          if (CONV) {
+            const int hw = p.Ho * p.Wo;
+            const int t = m / hw, rem = m - t * hw;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            const int y0 = oy * p.stride - p.pad_t, x0 = ox * p.stride - p.pad_l;
+            unsigned mk = 0; int bit = 0;
+            for (int it = 0; it < p.kt; ++it)
+              for (int iy = 0; iy < p.ky; ++iy)
+                for (int ix = 0; ix < p.kx; ++ix, ++bit) {
+                  const int tt = t + it - (p.kt >> 1), y = y0 + iy, x = x0 + ix;
+                  if (tt >= 0 && tt < p.T && y >= 0 && y < p.Hi && x >= 0 && x < p.Wi) mk |= 1u << bit;
+                }
+            const unsigned ap = (unsigned)(((t - (p.kt >> 1)) * p.Hi + y0) * p.Wi + x0 + cshift);
+            a_st[l] = ok ? (mk << 23) | ap : 0u;
+          } else {
+            a_st[l] = ok ? (unsigned)m * (unsigned)(p.C0 * 2) + ((l & 1) ? lc16_1 : lc16_0) : SENT;
+          }
+        }
+#pragma unroll
+        for (int l = 0; l < LB; ++l) {
+          const int rg = pw * LB + l;
+          const int lr = rg * 8 + lrow;                 // LDS row of the W tile; holds W row n0 + perm(lr)
+          const int part = lr / WTN, rem = lr % WTN;
+          const int jj = rem >> 4, i = rem & 15;
+          const int n = n0 + part * WTN + (i >> 2) * WID + jj * 4 + (i & 3);
+          b_off[l] = (n < p.N && kt_lo < kt_hi) ? (unsigned)n * (unsigned)(p.ldw * 2) + ((l & 1) ? lc16_1 : lc16_0) : SENT;
+        }
+        if (CONV) {
+          const int kt0 = kt_lo * BK;
+          const int tap = kt0 / Cin;
+          u_cb = kt0 - tap * Cin;
+          u_it = tap / (p.ky * p.kx);
+          const int r2 = tap - u_it * (p.ky * p.kx);
+          u_iy = r2 / p.kx; u_ix = r2 - u_iy * p.kx;
+        }
+      }
+      f16* As = smem + ld_slot * STAGE;
+      f16* Bs = As + BM * BK;
+      const int kt2 = (kt_lo + ld_ks) * BK * 2;
+      if (CONV) {
+        const int tapbit = 23 + (u_it * p.ky + u_iy) * p.kx + u_ix;
+        const int tappix = (u_it * p.Hi + u_iy) * p.Wi + u_ix;
+        const bool src0 = u_cb < p.C0;
+        const int Cs2 = (src0 ? p.C0 : p.C1) * 2;
+        const int soff = tappix * Cs2 + (src0 ? u_cb : u_cb - p.C0) * 2;
+        const __amdgpu_buffer_rsrc_t rs = src0 ? rA0 : rA1;
+#pragma unroll
+        for (int l = 0; l < LA; ++l) {
+          const unsigned off = (a_st[l] & 0x7FFFFFu) * (unsigned)Cs2 + ((l & 1) ? lc16_1 : lc16_0);
+          const unsigned voff = ((a_st[l] >> tapbit) & 1u) ? off : SENT;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(As + (pw * LA + l) * 8 * BK), 16, (int)voff, soff, 0, 0);
+        }
+        u_cb += BK;
+        if (u_cb >= Cin) { u_cb = 0; if (++u_ix == p.kx) { u_ix = 0; if (++u_iy == p.ky) { u_iy = 0; ++u_it; } } }
+      } else {
+#pragma unroll
+        for (int l = 0; l < LA; ++l)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, (lptr_t)(As + (pw * LA + l) * 8 * BK), 16, (int)a_st[l], kt2, 0, 0);
+      }
+#pragma unroll
+      for (int l = 0; l < LB; ++l)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(Bs + (pw * LB + l) * 8 * BK), 16, (int)b_off[l], kt2, 0, 0);
+      if (++ld_ks == nk) { ld_ks = 0; ++ld_ti; }
+      if (++ld_slot == NST) ld_slot = 0;
+    };
+    // prologue: steps 0 and 1; step 0 must have landed before the first barrier
+    if (total_it > 0) issue();
+    if (total_it > 1) { issue(); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA + LB) : "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#ifdef UG_GEMM_TRACE
+    const bool traced = p.trace && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && wave == 8;
+    unsigned* tr_lds = (unsigned*)(smem + NST * STAGE) + 2 * 24 * 5;
+#endif
+    for (int fi = 0; fi < total_it; ++fi) {
+      UG_STAMP(0);
+      if (fi + 2 < total_it) {
+        issue();                                                            // step fi+2 -> slot (fi+2) % 3
+        UG_STAMP(1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA + LB) : "memory");       // step fi+1 has landed
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      UG_STAMP(2);
+      __builtin_amdgcn_s_barrier();
+      UG_STAMP(3);
+#ifdef UG_GEMM_TRACE
+      if (traced && fi == 40) {
+        __builtin_amdgcn_s_waitcnt(0);
+        for (int i = lane; i < 24 * 5; i += 64) ((unsigned*)p.trace)[2 * 24 * 5 + i] = tr_lds[i];
+      }
+#endif
+    }
+    return;
+  }
+
+  // ================================= compute waves =================================
+  const int wm = wave / WNW, wn = wave % WNW;
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int l15 = lane & 15, g = lane >> 4;
+  const int sw = swz<BK>(l15);
+  int cp_ti = 0, cp_ks = 0, cp_slot = 0;
+  __builtin_amdgcn_s_barrier();          // step 0 published
+  asm volatile("" ::: "memory");
+#ifdef UG_GEMM_TRACE
+  const bool traced = p.trace && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (wave == 0 || wave == 4);
+  unsigned* tr_lds = (unsigned*)(smem + NST * STAGE) + (wave == 4 ? 24 * 5 : 0);
+#endif
+  for (int fi = 0; fi < total_it; ++fi) {
+    UG_STAMP(0);
+    const f16* Ab = smem + cp_slot * STAGE + (wm * WTM + l15) * BK;
+    const f16* Bb = smem + cp_slot * STAGE + BM * BK + (wn * WTN + l15) * BK;
+    if (++cp_slot == NST) cp_slot = 0;
+    {
+      f16x8 af[2][MT], bf[2][NT];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int ch = ((kk * 4 + g) ^ sw) * 8;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[kk][j] = *(const f16x8*)(Bb + j * 16 * BK + ch);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[kk][i] = *(const f16x8*)(Ab + i * 16 * BK + ch);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+      constexpr int R = MT + NT, Q = MT * NT;
+      __builtin_amdgcn_sched_group_barrier(0x100, R, 0);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x008, Q / R, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, Q - R * (Q / R), 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, Q, 0);
+    }
+    UG_STAMP(1);
+    if (++cp_ks == nk) {
+      cp_ks = 0;
+      const int tile = wslot + (cp_ti++) * nwg;
+      tile_epilogue<MT, NT, WTM, WTN>(p, acc, (tile / ntn) * BM, (tile % ntn) * BN, wm, wn, lane, out_off);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all fragment reads of this slot are done before it is handed back
+    UG_STAMP(2);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    UG_STAMP(3);
+#ifdef UG_GEMM_TRACE
+    if (traced && fi == 40) {
+      __builtin_amdgcn_s_waitcnt(0);
+      for (int i = lane; i < 24 * 5; i += 64) ((unsigned*)p.trace)[(wave == 4 ? 24 * 5 : 0) + i] = tr_lds[i];
+    }
+#endif
+  }
+}
+
+template <int WMW, int WNW>
+static void launch_ws(const GemmP& p, int batch, hipStream_t s) {
+  const int ntiles = cdiv(p.M, 256) * cdiv(p.N, 128);
+#ifdef UG_GEMM_TRACE
+  const size_t lds = 3 * (256 + 128) * 64 * sizeof(f16) + 2048;
+#else
+  const size_t lds = 3 * (256 + 128) * 64 * sizeof(f16);
+#endif
+  static bool attr = false;
+  if (!attr) {
+    UG_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<WMW, WNW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    UG_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<WMW, WNW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  const int split = p.splitk > 1 ? p.splitk : 1;
+  int gx = std::max(8, 256 / (split * batch));
+  gx = (gx / 8) * 8;
+  gx = std::min(gx, ntiles);
+  dim3 grid(gx, split, batch);
+  if (p.conv) hipLaunchKernelGGL((gemm_ws_kernel<WMW, WNW, true>), grid, dim3(768), lds, s, p);
+  else hipLaunchKernelGGL((gemm_ws_kernel<WMW, WNW, false>), grid, dim3(768), lds, s, p);
+}
+
 template <int BM, int BN, int NST, int WMW, int WNW>
 static void launch_ldr(const GemmP& p, int batch, hipStream_t s) {
   const int ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
@@ -905,6 +1174,9 @@ static void launch_cfg(int cfg, const GemmP& p, int batch, hipStream_t s) {
     // asymmetric-loader forms of the 8-wave tiles (gemm_ldr_kernel); need buffer addressing, else the symmetric kernel
     case 35: if (gemm_can_bufa(p, 64, true)) launch_ldr<256, 256, 2, 2, 4>(p, batch, s); else launch_mode<256, 256, 64, 2, 2, 4>(p, batch, s); break;
     case 39: if (gemm_can_bufa(p, 64, true)) launch_ldr<256, 128, 3, 2, 4>(p, batch, s); else launch_mode<256, 128, 64, 3, 2, 4>(p, batch, s); break;
+    // producer / consumer forms of the 256x128 tile (gemm_ws_kernel): wave tile 128x32 (59) and 64x64 (54, GEGLU-capable)
+    case 59: if (gemm_can_bufa(p, 64, true)) launch_ws<2, 4>(p, batch, s); else launch_mode<256, 128, 64, 3, 2, 4>(p, batch, s); break;
+    case 54: if (gemm_can_bufa(p, 64, true)) launch_ws<4, 2>(p, batch, s); else launch_mode<256, 128, 64, 3, 4, 2>(p, batch, s); break;
     case 34: if (gemm_can_bufa(p, 64, true)) launch_ldr<256, 64, 2, 4, 2>(p, batch, s); else launch_mode<256, 64, 64, 2, 4, 2>(p, batch, s); break;
     default: UG_REQUIRE(false, "unknown / pruned GEMM tile config");
   }
@@ -923,9 +1195,10 @@ int gemm_knobs_get() { return g_knobs; }
 // 8192^3 dense, the 512-channel VAE conv for im2col).  Checked against the full sweep of the clip's shapes the model's
 // pick is the measured best or within ~5 % of it.  Low-resolution levels (M <= 2048) are latency-bound, not
 // throughput-bound: they keep the measured rules below (64x64 tiles / split-K).
-struct TileCand { int id, bm, bn, percu; float dense, conv; bool geglu_ok; };   // id 35 = loader form of 15 (gemm_ldr_kernel)
+struct TileCand { int id, bm, bn, percu; float dense, conv; bool geglu_ok; };   // 35 = loader form of 15; 59 / 54 = producer / consumer 256x128
 static const TileCand kCands[] = {
-    {15, 256, 256, 1, 1200.f, 1130.f, true},  {35, 256, 256, 1, 1190.f, 1200.f, true},  {19, 256, 128, 1, 1050.f, 929.f, false}, {0, 128, 128, 2, 890.f, 1025.f, true},
+    {15, 256, 256, 1, 1200.f, 1190.f, true},  {35, 256, 256, 1, 1190.f, 1200.f, true},  {59, 256, 128, 1, 1143.f, 1154.f, false},
+    {54, 256, 128, 1, 1135.f, 1150.f, true},  {19, 256, 128, 1, 1044.f, 1002.f, false}, {0, 128, 128, 2, 890.f, 1025.f, true},
     {14, 256, 64, 2, 880.f, 883.f, false},    {1, 128, 64, 3, 757.f, 799.f, false},    {12, 64, 64, 5, 456.f, 652.f, false}};
 
 void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
@@ -938,7 +1211,7 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
     const long tiles = tm * tn * batch, slots = (long)c.percu * 256;
     float sc = (p.conv ? c.conv : c.dense) * ((float)p.M / (tm * c.bm)) * ((float)p.N / (tn * c.bn)) *
                ((float)tiles / (cdiv(tiles, slots) * slots));
-    if (c.id == 19 && p.conv && p.K <= 512) sc *= 1.15f;   // its 3-stage ring hides the short K loop's fill (temporal convs, K = 3C); in-situ it loses on dense K = 320
+    if (c.id == 19 && p.conv && p.K <= 512) sc *= 1.25f;   // its 3-stage ring hides the short K loop's fill (temporal convs, K = 3C); in-situ it loses on dense K = 320
     if (sc > best) { best = sc; cfg = c.id; }
   }
   // in-situ exception (tools/insitu_cfg_sweep.py): the level-0 down-projection (M = 76800, N = 320, K = 1280) re-reads its 197 MB
@@ -964,7 +1237,7 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
   } else if (plain_epi && p.conv && p.M <= 8192 && nk >= 256 && p.N >= 512) {
     cfg = 0; split = 4;   // 12x16 level, concatenated 2560-channel input: four K slices fill the last round (880 vs 816 TFLOP/s)
   }
-  if (g_force_cfg >= 0 && !(geglu && g_force_cfg != 0 && g_force_cfg != 4 && g_force_cfg != 8 && g_force_cfg != 15 && g_force_cfg != 35)) cfg = g_force_cfg;
+  if (g_force_cfg >= 0 && !(geglu && g_force_cfg != 0 && g_force_cfg != 4 && g_force_cfg != 8 && g_force_cfg != 15 && g_force_cfg != 35 && g_force_cfg != 54)) cfg = g_force_cfg;
   if (g_force_split >= 0) split = plain_epi ? std::max(1, g_force_split) : 1;
   *cfg_out = cfg; *split_out = split;
 }
@@ -989,7 +1262,7 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
   }
   int cfg = p.cfg_p1 - 1, split = p.splitk;
   if (cfg < 0 || split < 1) { int c2, s2; gemm_plan(p, batch, &c2, &s2); if (cfg < 0) cfg = c2; if (split < 1) split = s2; }
-  if (p.flags & UG_F_GEGLU) UG_REQUIRE(cfg == 0 || cfg == 4 || cfg == 8 || cfg == 15 || cfg == 35, "GEGLU needs a 64-column wave tile");
+  if (p.flags & UG_F_GEGLU) UG_REQUIRE(cfg == 0 || cfg == 4 || cfg == 8 || cfg == 15 || cfg == 35 || cfg == 54, "GEGLU needs a 64-column wave tile");
   p.splitk = split;
   if (split > 1) UG_REQUIRE(p.partial != nullptr, "split-K needs a partial buffer");
   launch_cfg(cfg, p, batch, s);
