@@ -322,13 +322,13 @@ def test_flash_attention_full_size_properties(engine):
 # ---------------------------------------------------------------------------------------------------
 # Cross-config race screen.  Every tile configuration accumulates K through the same 16x16x32 MFMA chain in the same
 # order, so (split-K aside) all of them must produce bit-identical outputs; a pipeline race in one kernel variant
-# (ring slot reuse, counted vmcnt, the asymmetric-loader kernels = configs 34 / 35 / 39, the producer / consumer kernels = 54 / 59) shows up as a difference.
+# (ring slot reuse, counted vmcnt, the asymmetric-loader kernels = configs 34 / 35 / 39, the producer / consumer kernels = 54 / 59 / 60) shows up as a difference.
 # ---------------------------------------------------------------------------------------------------
 def _force(engine, cfg):
     engine.lib.ug_tune_force(cfg, 1 if cfg >= 0 else -1)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 3, 4, 8, 12, 14, 19, 34, 35, 39, 54, 59])
+@pytest.mark.parametrize("cfg", [0, 1, 3, 4, 8, 12, 14, 19, 34, 35, 39, 54, 59, 60])
 def test_tile_configs_bitwise_identical_small_ragged(engine, cfg):
     rng = np.random.default_rng(100 + cfg)
     geglu = cfg in (0, 4, 8, 35, 54)

@@ -86,12 +86,18 @@ template <int BM, int BN, int BK, int NST, int WMW, int WNW> struct GemmOcc {
 #define UG_STAMP(slot) do {} while (0)
 #endif
 
+template <int N> struct HVec;
+template <> struct HVec<8> { typedef f16x8 type; };
+template <> struct HVec<4> { typedef f16x4 type; };
+
 // Per-tile epilogue shared by the GEMM kernels: the lane holds WID = 4*NT contiguous columns of rows
 // m0 + wm*WTM + i*16 + (lane & 15).  Clears the accumulators for the next tile.
 template <int MT, int NT, int WTM, int WTN>
 __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wm, int wn, int lane,
                                               long out_off) {
   constexpr int WID = 4 * NT;
+  constexpr int CH = (WID % 8 == 0) ? 8 : 4;   // vector width of the epilogue's loads / stores (WID = 20: 80-column wave tiles)
+  typedef typename HVec<CH>::type hvec;
   const int l15 = lane & 15, g = lane >> 4;
   const bool geglu = (p.flags & UG_F_GEGLU) != 0;
   const bool of32 = (p.flags & UG_F_OUT_F32) != 0;
@@ -115,25 +121,25 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][N
   const int ob = geglu ? nb / 2 : nb;          // first output column of this lane
   const bool full = (nb + WID <= p.N);
   const bool vec = full && ((p.ldo & 7) == 0) && (!p.R1 || (p.ldr1 & 7) == 0) &&
-                   (!p.R2 || (p.ldr2 & 7) == 0) && (OW % 8 == 0);
+                   (!p.R2 || (p.ldr2 & 7) == 0) && (OW % CH == 0);
   float bv[WID];
 #pragma unroll
   for (int e = 0; e < WID; ++e) bv[e] = 0.f;
   if (full) {
     if (p.bias) {
 #pragma unroll
-      for (int e = 0; e < WID; e += 8) {
-        const f16x8 b = *(const f16x8*)(p.bias + nb + e);
+      for (int e = 0; e < WID; e += CH) {
+        const hvec b = *(const hvec*)(p.bias + nb + e);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) bv[e + q] += (float)b[q];
+        for (int q = 0; q < CH; ++q) bv[e + q] += (float)b[q];
       }
     }
     if (p.bias2) {
 #pragma unroll
-      for (int e = 0; e < WID; e += 8) {
-        const f16x8 b = *(const f16x8*)(p.bias2 + nb + e);
+      for (int e = 0; e < WID; e += CH) {
+        const hvec b = *(const hvec*)(p.bias2 + nb + e);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) bv[e + q] += (float)b[q];
+        for (int q = 0; q < CH; ++q) bv[e + q] += (float)b[q];
       }
     }
   } else {
@@ -174,36 +180,36 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][N
     }
     if (vec) {
 #pragma unroll
-      for (int e = 0; e < OW; e += 8) {
-        float o[8];
+      for (int e = 0; e < OW; e += CH) {
+        float o[CH];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] = p.c0 * v[e + q];
+        for (int q = 0; q < CH; ++q) o[q] = p.c0 * v[e + q];
         if (p.R1) {
-          const f16x8 r = *(const f16x8*)(p.R1 + (long)m * p.ldr1 + ob + e);
+          const hvec r = *(const hvec*)(p.R1 + (long)m * p.ldr1 + ob + e);
 #pragma unroll
-          for (int q = 0; q < 8; ++q) o[q] += p.c1 * (float)r[q];
+          for (int q = 0; q < CH; ++q) o[q] += p.c1 * (float)r[q];
         }
         if (p.R2) {
-          const f16x8 r = *(const f16x8*)(p.R2 + (long)m * p.ldr2 + ob + e);
+          const hvec r = *(const hvec*)(p.R2 + (long)m * p.ldr2 + ob + e);
 #pragma unroll
-          for (int q = 0; q < 8; ++q) o[q] += p.c2 * (float)r[q];
+          for (int q = 0; q < CH; ++q) o[q] += p.c2 * (float)r[q];
         }
         if (p.act == UG_ACT_SILU) {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) o[q] = silu_f(o[q]);
+          for (int q = 0; q < CH; ++q) o[q] = silu_f(o[q]);
         } else if (p.act == UG_ACT_GELU) {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) o[q] = gelu_f(o[q]);
+          for (int q = 0; q < CH; ++q) o[q] = gelu_f(o[q]);
         }
         if (of32) {
           float* O = (float*)p.Out + out_off + orow * p.ldo + ob + e;
-          *(f32x4*)O = (f32x4){o[0], o[1], o[2], o[3]};
-          *(f32x4*)(O + 4) = (f32x4){o[4], o[5], o[6], o[7]};
-        } else {
-          f16x8 h;
 #pragma unroll
-          for (int q = 0; q < 8; ++q) h[q] = (f16)o[q];
-          *(f16x8*)((f16*)p.Out + out_off + orow * p.ldo + ob + e) = h;
+          for (int q = 0; q < CH; q += 4) *(f32x4*)(O + q) = (f32x4){o[q], o[q + 1], o[q + 2], o[q + 3]};
+        } else {
+          hvec h;
+#pragma unroll
+          for (int q = 0; q < CH; ++q) h[q] = (f16)o[q];
+          *(hvec*)((f16*)p.Out + out_off + orow * p.ldo + ob + e) = h;
         }
       }
     } else {
@@ -799,15 +805,16 @@ static bool gemm_can_bufa(const GemmP& p, int BK, bool packed) {
 // publishes step i+1 and frees slot i % 3.  Only producers ever have loads in flight in the K loop, so the epilogue's
 // global traffic (consumers) needs no drain logic.  LDS image, W row permutation, MFMA chain order and epilogue are those
 // of gemm_kernel: outputs are bit-identical.
-template <int WMW, int WNW, bool CONV>
+template <int BN, int WMW, int WNW, bool CONV>
 __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(const GemmP p) {
-  constexpr int BM = 256, BN = 128, BK = 64, NST = 3;
+  constexpr int BM = 256, BK = 64, NST = 3;
+  static_assert(BN % 32 == 0 && BN <= 160, "ring of three 256 x BN x 64 slots must fit 160 KiB");
   static_assert(WMW * WNW == 8, "eight consumer waves");
   constexpr unsigned SENT = 0x80000000u;
   constexpr int WTM = BM / WMW, WTN = BN / WNW;
   constexpr int MT = WTM / 16, NT = WTN / 16;
   constexpr int WID = 4 * NT;
-  constexpr int LA = 8, LB = 4;                      // 1 KiB loads per producer wave per K-step (32 A + 16 B pieces / 4 waves)
+  constexpr int LA = 8, LB = BN / 32;                // 1 KiB loads per producer wave per K-step (32 A + BN/8 B pieces / 4 waves)
   constexpr int STAGE = (BM + BN) * BK;
   extern __shared__ __attribute__((aligned(16))) f16 smem[];
 
@@ -887,7 +894,7 @@ __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(const GemmP p) {
           const int part = lr / WTN, rem = lr % WTN;
           const int jj = rem >> 4, i = rem & 15;
           const int n = n0 + part * WTN + (i >> 2) * WID + jj * 4 + (i & 3);
-          b_off[l] = (n < p.N && kt_lo < kt_hi) ? (unsigned)n * (unsigned)(p.ldw * 2) + ((l & 1) ? lc16_1 : lc16_0) : SENT;
+          b_off[l] = (n < p.N && kt_lo < kt_hi) ? (unsigned)n * (unsigned)(p.ldw * 2) + ((rg & 1) ? lc16_1 : lc16_0) : SENT;
         }
         if (CONV) {
           const int kt0 = kt_lo * BK;
@@ -1026,18 +1033,18 @@ __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(const GemmP p) {
   }
 }
 
-template <int WMW, int WNW>
+template <int BN, int WMW, int WNW>
 static void launch_ws(const GemmP& p, int batch, hipStream_t s) {
-  const int ntiles = cdiv(p.M, 256) * cdiv(p.N, 128);
+  const int ntiles = cdiv(p.M, 256) * cdiv(p.N, BN);
 #ifdef UG_GEMM_TRACE
-  const size_t lds = 3 * (256 + 128) * 64 * sizeof(f16) + 2048;
+  const size_t lds = 3 * (256 + BN) * 64 * sizeof(f16) + 2048;
 #else
-  const size_t lds = 3 * (256 + 128) * 64 * sizeof(f16);
+  const size_t lds = 3 * (256 + BN) * 64 * sizeof(f16);
 #endif
   static bool attr = false;
   if (!attr) {
-    UG_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<WMW, WNW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    UG_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<WMW, WNW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    UG_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<BN, WMW, WNW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    UG_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<BN, WMW, WNW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
   const int split = p.splitk > 1 ? p.splitk : 1;
@@ -1045,8 +1052,8 @@ static void launch_ws(const GemmP& p, int batch, hipStream_t s) {
   gx = (gx / 8) * 8;
   gx = std::min(gx, ntiles);
   dim3 grid(gx, split, batch);
-  if (p.conv) hipLaunchKernelGGL((gemm_ws_kernel<WMW, WNW, true>), grid, dim3(768), lds, s, p);
-  else hipLaunchKernelGGL((gemm_ws_kernel<WMW, WNW, false>), grid, dim3(768), lds, s, p);
+  if (p.conv) hipLaunchKernelGGL((gemm_ws_kernel<BN, WMW, WNW, true>), grid, dim3(768), lds, s, p);
+  else hipLaunchKernelGGL((gemm_ws_kernel<BN, WMW, WNW, false>), grid, dim3(768), lds, s, p);
 }
 
 template <int BM, int BN, int NST, int WMW, int WNW>
@@ -1175,8 +1182,9 @@ static void launch_cfg(int cfg, const GemmP& p, int batch, hipStream_t s) {
     case 35: if (gemm_can_bufa(p, 64, true)) launch_ldr<256, 256, 2, 2, 4>(p, batch, s); else launch_mode<256, 256, 64, 2, 2, 4>(p, batch, s); break;
     case 39: if (gemm_can_bufa(p, 64, true)) launch_ldr<256, 128, 3, 2, 4>(p, batch, s); else launch_mode<256, 128, 64, 3, 2, 4>(p, batch, s); break;
     // producer / consumer forms of the 256x128 tile (gemm_ws_kernel): wave tile 128x32 (59) and 64x64 (54, GEGLU-capable)
-    case 59: if (gemm_can_bufa(p, 64, true)) launch_ws<2, 4>(p, batch, s); else launch_mode<256, 128, 64, 3, 2, 4>(p, batch, s); break;
-    case 54: if (gemm_can_bufa(p, 64, true)) launch_ws<4, 2>(p, batch, s); else launch_mode<256, 128, 64, 3, 4, 2>(p, batch, s); break;
+    case 59: if (gemm_can_bufa(p, 64, true)) launch_ws<128, 2, 4>(p, batch, s); else launch_mode<256, 128, 64, 3, 2, 4>(p, batch, s); break;
+    case 54: if (gemm_can_bufa(p, 64, true)) launch_ws<128, 4, 2>(p, batch, s); else launch_mode<256, 128, 64, 3, 4, 2>(p, batch, s); break;
+    case 60: if (gemm_can_bufa(p, 64, true)) launch_ws<160, 4, 2>(p, batch, s); else launch_mode<256, 64, 64, 2, 4, 2>(p, batch, s); break;   // 256x160: every UNet width is a multiple of 160
     case 34: if (gemm_can_bufa(p, 64, true)) launch_ldr<256, 64, 2, 4, 2>(p, batch, s); else launch_mode<256, 64, 64, 2, 4, 2>(p, batch, s); break;
     default: UG_REQUIRE(false, "unknown / pruned GEMM tile config");
   }
