@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Sum a PMC counter over the GEMM-family dispatches (gemm_kernel, gemm_ldr_kernel) of a rocprofv3 counter_collection CSV and,
+"""Sum a PMC counter over the GEMM-family dispatches (gemm_kernel, gemm_ldr_kernel, gemm_ws_kernel) of a rocprofv3 counter_collection CSV and,
 given the FETCH_SIZE and WRITE_SIZE pass directories, write the per-launch traffic summary bench.py reads."""
 import csv, glob, json, os, sys
 out = {}
@@ -8,7 +8,8 @@ for d in sys.argv[1:]:
     tot, n, name = 0.0, 0, None
     for f in files:
         for row in csv.DictReader(open(f)):
-            if "gemm_kernel" in row.get("Kernel_Name", "") or "gemm_ldr_kernel" in row.get("Kernel_Name", ""):
+            kn = row.get("Kernel_Name", "")
+            if "gemm_kernel" in kn or "gemm_ldr_kernel" in kn or "gemm_ws_kernel" in kn:
                 tot += float(row["Counter_Value"]); n += 1; name = row["Counter_Name"]
     out[name or os.path.basename(d)] = {"sum": tot, "dispatch_rows": n}
 print(json.dumps(out))
