@@ -151,12 +151,14 @@ def main():
                                "frac": round(ach / PEAK_TFLOPS_F16, 4), "traffic": None,
                                "kernel": "gemm_kernel<...> + gemm_ws_kernel<...> + gemm_ldr_kernel<...> (all linear / 3x3 / 1x1 / temporal-conv / attention GEMM launches)",
                                "launches": g_calls, "avg_launch_us": round(g_ms * 1000.0 / max(g_calls, 1), 2),
-                               "algorithmic_tflop": round(g_fl / 1e12, 2)}
+                               "algorithmic_tflop": round(g_fl / 1e12, 2),
+                               "algorithmic_bytes_per_launch": round(sum(v.get("bytes", 0) for v in gem.values()) / max(g_calls, 1))}
             try:   # HBM traffic of the same kernel family from the committed PMC passes (tools/pmc_traffic.sh)
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_gemm.json")))
                 res["roofline"]["traffic"] = round(pm["hbm_bytes_per_launch"])
                 res["roofline"]["traffic_note"] = ("bytes per GEMM-family launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes "
-                                                   "on a 3-step clip (profiles/r01_pmc_traffic_gemm.json), FETCH doubled per the gfx950 note")
+                                                   "on a 3-step clip (profiles/r01_pmc_traffic_gemm.json), FETCH doubled per the gfx950 note; algorithmic bytes per launch of that "
+                                                   "3-step mix: 138 MB (this line's algorithmic_bytes_per_launch is the 25-step mix)")
             except Exception:
                 pass
             res["kernel_ms"] = {k: round(v["ms"], 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}

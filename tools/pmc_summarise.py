@@ -19,7 +19,7 @@ if "FETCH_SIZE" in out and "WRITE_SIZE" in out and out["FETCH_SIZE"]["dispatch_r
     n = out["FETCH_SIZE"]["dispatch_rows"]
     rd = out["FETCH_SIZE"]["sum"] * 1024 * 2 / n          # counters are in KB; FETCH doubled (gfx950 note)
     wr = out["WRITE_SIZE"]["sum"] * 1024 / out["WRITE_SIZE"]["dispatch_rows"]
-    json.dump({"workload": "tools/one_clip.py 3 (25x384x512 clip, 3 Euler steps, CLIP + VAE enc/dec), GEMM-family dispatches only",
+    json.dump({"workload": "tools/one_clip.py 3 (25x384x512 clip, 3 Euler steps, CLIP + VAE enc/dec; rocprofv3 counter collection crashes on the 25-step run), GEMM-family dispatches only",
                "dispatches": n, "FETCH_SIZE_sum_KB": out["FETCH_SIZE"]["sum"], "WRITE_SIZE_sum_KB": out["WRITE_SIZE"]["sum"],
                "correction": "FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B on wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported",
                "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,

@@ -85,7 +85,12 @@ static void run_gemm(Ctx& c, GemmP p, int batch, const char* tag) {
   if (split > 1) p.partial = c.ws.get<float>((long)split * p.M * p.N);
   {
     // algorithmic FLOPs: a sub-pixel phase of an upsample conv stands for 9/4 of the MACs it executes
-    ProfScope ps(c, nm, 2.0 * p.M * p.N * (double)p.K * batch * (p.up_phase ? 2.25 : 1.0), 0);
+    // algorithmic bytes: every operand element once (the im2col view counts its source tensors, not the 9x gather), fp16
+    const double nout = (p.flags & UG_F_GEGLU) ? p.N / 2 : p.N;
+    const double a_el = p.conv ? (double)p.T * p.Hi * p.Wi * (p.C0 + p.C1) : (double)p.M * p.K;
+    const double bytes = 2.0 * batch * (a_el + (double)p.N * p.K + (double)p.M * nout * ((p.flags & UG_F_OUT_F32) ? 2 : 1) +
+                                        (p.R1 ? (double)p.M * nout : 0.0) + (p.R2 ? (double)p.M * nout : 0.0));
+    ProfScope ps(c, nm, 2.0 * p.M * p.N * (double)p.K * batch * (p.up_phase ? 2.25 : 1.0), bytes);
     launch_gemm(p, batch, c.stream);
   }
   c.ws.release(mk);
