@@ -224,3 +224,33 @@ def test_full_architecture_unet_and_vae_decoder_small_clip():
         assert np.abs(gotv - refv).max() < 2e-2, np.abs(gotv - refv).max()
     finally:
         pipe.engine.close()
+
+
+def test_full_architecture_clip_and_vae_encoder_small_clip():
+    """CLIP ViT-H/14 (632 M parameters, 32 layers, 16 heads of 80) and the full VAE encoder with seeded random weights: HIP vs the oracle.
+    The CLIP oracle itself is pinned against transformers.CLIPVisionModelWithProjection (tests/test_oracle_structure.py), so this ties the
+    HIP tower to the real implementation at full size."""
+    from oracle.clip import clip_preprocess
+    from unigeo_amd import weights as W
+    from unigeo_amd.pipeline import DepthCrafterPipelineHIP
+    u, v, c = W.tiny_cfgs()[0], W.VAECfg(), W.CLIPCfg()
+    su, sv, sc = (W.random_state(W.unet_manifest(u), 21), W.random_state(W.vae_manifest(v), 22), W.random_state(W.clip_manifest(c), 23))
+    pipe = DepthCrafterPipelineHIP.from_state(su, sv, sc, cfgs=(u, v, c), workspace_bytes=8 << 30, persist_bytes=4 << 30)
+    try:
+        rng = np.random.default_rng(6)
+        frames = h16(rng.uniform(0, 1, (2, 64, 128, 3)))
+        got = pipe.engine.clip_embed(frames)
+        clip = oracle_clip(c, sc)
+        with torch.no_grad():
+            ref = clip(clip_preprocess(torch.from_numpy(frames).permute(0, 3, 1, 2) * 2.0 - 1.0)).numpy()
+        del clip
+        assert got.shape == ref.shape == (2, 1024)
+        assert_close(got, ref, 2e-2, "full-architecture CLIP image embedding")
+        video = h16(rng.uniform(-1, 1, (2, 64, 64, 3)))
+        gote = pipe.engine.vae_encode(video)
+        vae = oracle_vae(v, sv)
+        with torch.no_grad():
+            refe = vae.encode_mode(torch.from_numpy(video).permute(0, 3, 1, 2)).numpy()
+        assert_close(gote, refe, 2e-2, "full-architecture VAE encode (posterior mode)")
+    finally:
+        pipe.engine.close()
