@@ -254,3 +254,29 @@ def test_full_architecture_clip_and_vae_encoder_small_clip():
         assert_close(gote, refe, 2e-2, "full-architecture VAE encode (posterior mode)")
     finally:
         pipe.engine.close()
+
+
+def test_full_architecture_pipeline_end_to_end():
+    """The whole hot path - CLIP embed, noise-augmented VAE encode, 2 Karras-Euler steps of the 1.52 B-parameter UNet, temporal VAE
+    decode, depth post-processing - at the real architecture sizes (seeded random weights) on a 2-frame 64x64 clip, against the oracle's
+    run of the same pipeline with the same noise.  Frames live in [0,1]: the bound is absolute."""
+    from oracle.pipeline import run_pipeline
+    from unigeo_amd import weights as W
+    from unigeo_amd.pipeline import DepthCrafterPipelineHIP, make_noise
+    u, v, c = W.UNetCfg(), W.VAECfg(), W.CLIPCfg()
+    su, sv, sc = (W.random_state(W.unet_manifest(u), 31), W.random_state(W.vae_manifest(v), 32), W.random_state(W.clip_manifest(c), 33))
+    pipe = DepthCrafterPipelineHIP.from_state(su, sv, sc, cfgs=(u, v, c), workspace_bytes=8 << 30)
+    try:
+        T, H, Wd = 2, 64, 64
+        rng = np.random.default_rng(9)
+        frames = (rng.uniform(0, 255, (T, H, Wd, 3)).astype(np.uint8)).astype(np.float32) / 255.0
+        nl, na = make_noise(T, H, Wd, seed=4)
+        res = pipe(frames, num_inference_steps=2, window_size=T, noise_latents=nl, noise_aug=na)
+        ref = run_pipeline(oracle_unet(u, su), oracle_vae(v, sv), oracle_clip(c, sc), frames, torch.from_numpy(nl), torch.from_numpy(na),
+                           steps=2, chunk=8)
+        err = np.abs(res.frames[0] - ref).max()
+        print(f"full-architecture pipeline: max |HIP - oracle| = {err:.3e} on frames in [0,1]")
+        assert res.frames[0].shape == ref.shape and np.isfinite(res.frames[0]).all()
+        assert err < 3e-2, err
+    finally:
+        pipe.engine.close()
