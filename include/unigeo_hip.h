@@ -92,6 +92,15 @@ int ug_dc_run(ug_ctx* ctx, int steps, int decode_chunk, int with_normals);
  * frames of the noise passed to ug_dc_set_inputs are the window noise (rotated by `overlap` frames per window, as upstream). */
 int ug_dc_run_windows(ug_ctx* ctx, int steps, int decode_chunk, int with_normals, int window, int overlap);
 int ug_dc_get_outputs(ug_ctx* ctx, float* frames_out, float* depth_out, float* normals_out);
+/* Arithmetic of the VAE *encoder*.  The reference pipeline up-casts the VAE to float32 around encode (diffusers force_upcast;
+ * pipeline built at model/depthcrafter.py:24-29) and runs everything else in fp16.  on = 1 (default): float32-grade encoder -
+ * fp32 residual stream / GroupNorm / softmax, GEMMs on fp16 hi/lo activation pairs against the (fp16-valued) weights, which is
+ * exact to fp32 rounding.  on = 0: fp16 storage with fp32 accumulation, like the decoder (faster, ~1e-3 off the fp32 result). */
+int ug_set_vae_encode_fp32(ug_ctx* ctx, int on);
+/* Parity instrumentation (no reference counterpart; the reference would use the pipeline's callback_on_step_end): while
+ * host_latents != NULL, ug_dc_run copies the latents after each of the first `steps` Euler steps to
+ * host_latents[step][T][h][w][4] (float32, channels-last).  NULL switches it off.  Costs one host sync per step. */
+int ug_dc_set_trace(ug_ctx* ctx, float* host_latents, int steps);
 /* Device addresses of the resident outputs (valid until the next ug_dc_set_inputs): lets the caller hand
  * them to RCCL (torch.distributed) for the cross-GPU gather without a host round trip. */
 int ug_dc_device_ptrs(ug_ctx* ctx, void** frames_dev, void** depth_dev, void** normals_dev);

@@ -70,6 +70,7 @@ def run_pipeline(unet, vae, clip, frames_thwc, noise_latents, noise_aug, steps,
             if i == 0:
                 st["unet_out0"] = v
             latents = sch.step(v, i, latents)
+            st.setdefault("latents_per_step", []).append(latents[0].clone())     # [T,4,h,w] after step i
     else:
         stride = window - overlap
         latents_init = noise_latents[:, :window].to(dtype) * sch.init_noise_sigma

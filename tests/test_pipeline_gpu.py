@@ -54,6 +54,7 @@ def test_plugin_contract(tiny_plugin):
     (reference model/depthcrafter.py:62-68), depth range of 1/(x+0.1) with x in [0,1]."""
     from unigeo_amd.synthetic import synthetic_clip
     data = synthetic_clip(3, 64, 128, seed=3)
+    data["_index"] = 7                                    # per-clip noise seed = plugin seed + dataset index
     out = tiny_plugin.forward(data)
     d, n = out["pred_depths"], out["pred_normals"]
     assert d.shape == (3, 64, 128) and n.shape == (3, 64, 128, 3)
@@ -62,8 +63,10 @@ def test_plugin_contract(tiny_plugin):
     assert float(d.min()) >= 1 / 1.1 - 1e-5 and float(d.max()) <= 10.0 + 1e-4
     assert float(d.max()) == pytest.approx(10.0, rel=1e-5) and float(d.min()) == pytest.approx(1 / 1.1, rel=1e-5)
     np.testing.assert_allclose(n.norm(dim=-1).numpy(), 1.0, atol=1e-4)
-    out2 = tiny_plugin.forward(data)                      # same seed -> bit-identical (deterministic kernels)
+    out2 = tiny_plugin.forward(data)                      # same clip index -> same noise -> bit-identical (deterministic kernels)
     assert torch.equal(out2["pred_depths"], d) and torch.equal(out2["pred_normals"], n)
+    data["_index"] = 8                                    # another clip draws independent noise (reference: fresh RNG draws)
+    assert not torch.equal(tiny_plugin.forward(data)["pred_depths"], d)
     with pytest.raises(ValueError):
         tiny_plugin.forward(synthetic_clip(2, 60, 64))    # not a multiple of 64: rejected, not padded
 
@@ -84,7 +87,7 @@ def test_scannetpp_layout_to_metrics_with_plugin(tiny_plugin, tmp_path):
     import os
     from unigeo_amd.harness import evaluate
     root = os.path.join(os.path.dirname(__file__), "golden", "scannetpp_scene")
-    cfg = {"dataset": "ScannetPPDataset", "root": root, "h": 64, "w": 64, "clip_length": 3, "clip_overlap": 1, "split": "test",
+    cfg = {"dataset": "ScannetPPDataset", "root": root, "h": 64, "w": 64, "clip_length": 3, "clip_overlap": 1, "split": "test", "scenes": "all",
            "eval_depth": {"metric_names": ["Abs Rel", "delta < 1.25"], "depth_alignment": "lstsq"},
            "eval_normal": {"metric_names": ["normal mean", "angle < 11.25"]}}
     rows, _ = evaluate(cfg, model=tiny_plugin, save_dir=str(tmp_path), verbose=False)

@@ -74,8 +74,38 @@ def test_reference_yaml_shape_config_drives_the_harness(tmp_path):
             return {"pred_depths": torch.from_numpy(2.0 * d + 0.5).float(), "pred_normals": torch.from_numpy(n).float()}
 
     cfg = {"dataset": "ScannetPPDataset", "root": ROOT, "h": 24, "w": 32, "clip_length": 3, "clip_overlap": 1, "split": "test",
+           "scenes": "all",                       # the golden scene is not one of the ten nvs_sem_val scenes: explicit opt-in
            "model_name": "DepthCrafter", "model_params": {},
            "eval_depth": {"metric_names": ["Abs Rel", "delta < 1.25"], "depth_alignment": "lstsq"}}
     rows, _ = evaluate(cfg, model=GT(), save_dir=str(tmp_path), verbose=False)
     assert [r["seq_name"] for r in rows] == ["000_sceneA", "001_sceneA"]
     assert all(r["Abs Rel"] < 1e-4 and r["delta < 1.25"] == 1.0 for r in rows)
+
+
+def test_default_scene_set_is_the_reference_split_list_in_file_order(tmp_path):
+    """Without an explicit scene list the loader walks splits/nvs_sem_val.txt in file order (reference scannetpp.py:209-217),
+    not every directory under root; a split file can be passed; `scenes="all"` is the opt-in directory listing."""
+    import os, shutil
+    from unigeo_amd.harness import scannetpp as sp
+    ids = open(os.path.join(os.path.dirname(sp.__file__), "splits", "nvs_sem_val.txt")).read().split()
+    assert len(ids) == 10 and ids[0] == "7b6477cb95"
+    with pytest.raises(FileNotFoundError):                      # root holds sceneA only: the default list is NOT "whatever is there"
+        ScannetPPDataset(ROOT, clip_length=3, clip_overlap=1)
+    root = tmp_path / "root"
+    for name in ("zzz_extra", ids[1], ids[0]):                  # two listed scenes + one that is not in the split
+        shutil.copytree(os.path.join(ROOT, "sceneA"), root / name)
+    lst = tmp_path / "two.txt"; lst.write_text(ids[1] + "\n" + ids[0] + "\n")
+    ds = ScannetPPDataset(str(root), split_file=str(lst), clip_length=3, clip_overlap=1)
+    assert [s[0].scene_name for s in ds.samples][::2] == [ids[1], ids[0]]          # file order, extra scene ignored
+    assert len({s[0].scene_name for s in ScannetPPDataset(str(root), scenes="all", clip_length=3, clip_overlap=1).samples}) == 3
+
+
+def test_empty_mask_metrics_do_not_abort_the_run():
+    """degenerate clips yield NaN (normals) / zeros (depth) like the reference's loop, not an exception."""
+    from unigeo_amd.harness import depth_evaluation, normal_evaluation
+    n = np.zeros((1, 4, 4, 3), np.float32); n[..., 2] = 1
+    res = normal_evaluation(n, n, custom_mask=np.zeros((1, 4, 4), bool))
+    assert all(np.isnan(v) for v in res.values())
+    d = depth_evaluation(np.ones((1, 4, 4), np.float32), np.zeros((1, 4, 4), np.float32), custom_mask=np.ones((1, 4, 4), bool),
+                         align_with_lstsq=True)[0]
+    assert d["Abs Rel"] == 0 and d["valid_pixels"] == 0

@@ -4,15 +4,17 @@ full topology (every block type, skip-concats, up/down-sampling, spatial + tempo
 oracle finishes in seconds.
 
 Tolerances (written per test): the engine stores every activation in fp16 (fp32 accumulate); the oracle is
-fp32 throughout.  One op costs <= ~1e-3 of the output scale (tests/test_ops_gpu.py); a stage chains
-O(100) of them, so the stage bound is 2e-2 of the output scale.  north_star's 1e-3 is vs an fp16
-*reference* (same storage roundings); see DESIGN.md "Numerics".
+fp32 throughout.  Every bound below is <= ~2x the error MEASURED on MI355X for that case (the measured values are
+printed as PARITY lines and committed under profiles/r02_parity_measured.jsonl): 1.1e-3 - 2.2e-3 of the output scale
+for a stage, 3e-3 - 7.6e-3 absolute on decoded frames in [0,1] for a whole pipeline.  The kernels are deterministic, so the
+measured value is reproduced bit for bit from run to run and box to box.  north_star's 1e-3 is vs an fp16 *reference*
+(same storage roundings); see DESIGN.md "Numerics".
 """
 import numpy as np
 import pytest
 import torch
 
-from util import assert_close, h16, rel_err
+from util import assert_abs, assert_close, h16, rel_err, report
 from oracle_build import oracle_clip, oracle_unet, oracle_vae
 
 pytestmark = pytest.mark.gpu
@@ -39,16 +41,24 @@ def test_clip_embed(tiny):
     with torch.no_grad():
         v = torch.from_numpy(frames).permute(0, 3, 1, 2) * 2.0 - 1.0
         ref = tiny["clip"](clip_preprocess(v)).numpy()
-    assert_close(got, ref, 1e-2, "CLIP image embedding")
+    assert_close(got, ref, 2.5e-3, "CLIP image embedding")
 
 
 def test_vae_encode(tiny):
+    """Default = the reference's float32 encoder (force_upcast): fp32-grade arithmetic on fp16 hi/lo activation pairs
+    (kernels/wide.hip); the output is the pipeline's fp16 latent, so the floor is one fp16 rounding (2^-11 = 4.9e-4)."""
     rng = np.random.default_rng(1)
     video = h16(rng.uniform(-1, 1, (2, 64, 64, 3)))
-    got = tiny["eng"].vae_encode(video)
     with torch.no_grad():
         ref = tiny["vae"].encode_mode(torch.from_numpy(video).permute(0, 3, 1, 2)).numpy()
-    assert_close(got, ref, 2e-2, "VAE encode (posterior mode)")
+    got = tiny["eng"].vae_encode(video)
+    assert_close(got, ref, 6e-4, "tiny VAE encode, float32-grade (posterior mode, fp16 output)")
+    tiny["eng"].set_vae_encode_fp32(False)
+    try:
+        got16 = tiny["eng"].vae_encode(video)
+    finally:
+        tiny["eng"].set_vae_encode_fp32(True)
+    assert_close(got16, ref, 4e-3, "tiny VAE encode, fp16 storage (posterior mode)")
 
 
 @pytest.mark.parametrize("T", [1, 3])
@@ -60,8 +70,7 @@ def test_vae_decode(tiny, T):
         fr = tiny["vae"].decode(torch.from_numpy(z), T)
         ref = (fr / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy()
     # frames live in [0,1]: bound the absolute error
-    assert np.isfinite(got).all()
-    assert np.abs(got - ref).max() < 2e-2, np.abs(got - ref).max()
+    assert_abs(got, ref, 5e-3, f"tiny VAE decode T={T} (frames in [0,1])")
 
 
 @pytest.mark.parametrize("T,h,w", [(3, 8, 8), (5, 8, 16)])
@@ -75,7 +84,7 @@ def test_unet_forward(tiny, T, h, w):
     with torch.no_grad():
         ref = tiny["unet"](torch.from_numpy(x)[None], torch.tensor(tstep), torch.from_numpy(emb)[None],
                            torch.tensor([[7.0, 127.0, 0.02]]))[0].numpy()
-    assert_close(got, ref, 2e-2, "UNet forward")
+    assert_close(got, ref, 4.5e-3, "UNet forward")
 
 
 def test_pipeline_end_to_end(tiny):
@@ -91,8 +100,7 @@ def test_pipeline_end_to_end(tiny):
     got = res.frames[0]
     assert got.shape == ref.shape == (T, H, W, 3)
     assert np.isfinite(got).all()
-    err = np.abs(got - ref).max()
-    assert err < 3e-2, f"decoded frames differ by {err}"
+    assert_abs(got, ref, 1e-2, "tiny pipeline end to end, 2 steps (frames in [0,1])")
     # wrapper post-processing (channel mean, clip-global min-max, 1/(x+0.1)) done on device
     dref = np.stack(depth_from_frames(got), 0)
     assert_close(res.depth, dref, 1e-5, "on-device depth post-processing")
@@ -116,7 +124,7 @@ def test_unet_fp16_accuracy_matches_a_torch_fp16_run(tiny):
         t16 = m16(torch.from_numpy(x)[None].half(), torch.tensor(ts), torch.from_numpy(emb)[None].half(), ids.half())[0].float().numpy()
     got = tiny["eng"].unet_forward(x, ts, emb)
     e_hip, e16 = rel_err(got, ref), rel_err(t16, ref)
-    print(f"UNet: |HIP - fp32| = {e_hip:.2e}, |torch fp16 - fp32| = {e16:.2e}")
+    report("tiny UNet: |HIP - fp32|", e_hip); report("tiny UNet: |torch fp16 - fp32|", e16)
     assert e_hip <= 1.25 * e16 + 2e-4, (e_hip, e16)
 
 
@@ -131,7 +139,7 @@ def test_vae_decode_fp16_accuracy_matches_a_torch_fp16_run(tiny):
     ref01 = np.clip(ref / 2 + 0.5, 0, 1).transpose(0, 2, 3, 1)
     t01 = np.clip(t16 / 2 + 0.5, 0, 1).transpose(0, 2, 3, 1)
     e_hip, e16 = np.abs(got - ref01).max(), np.abs(t01 - ref01).max()
-    print(f"VAE decode: |HIP - fp32| = {e_hip:.2e}, |torch fp16 - fp32| = {e16:.2e}")
+    report("tiny VAE decode: |HIP - fp32|", e_hip); report("tiny VAE decode: |torch fp16 - fp32|", e16)
     assert e_hip <= 1.25 * e16 + 5e-4, (e_hip, e16)
 
 
@@ -147,8 +155,8 @@ def test_pipeline_edge_cases(tiny, T, H, W, steps, chunk):
     ref = run_pipeline(tiny["unet"], tiny["vae"], tiny["clip"], frames, torch.from_numpy(nl), torch.from_numpy(na),
                        steps=steps, chunk=chunk)
     got = res.frames[0]
-    assert got.shape == ref.shape and np.isfinite(got).all()
-    assert np.abs(got - ref).max() < 3e-2, np.abs(got - ref).max()
+    assert got.shape == ref.shape
+    assert_abs(got, ref, 1.2e-2, f"tiny pipeline edge case T={T} {H}x{W} steps={steps} chunk={chunk}")
 
 
 def test_frame_count_limits(tiny):
@@ -162,7 +170,7 @@ def test_frame_count_limits(tiny):
     nl, na = make_noise(T, H, W, seed=1)
     res = tiny["pipe"](frames, num_inference_steps=1, window_size=T, noise_latents=nl, noise_aug=na)
     ref = run_pipeline(tiny["unet"], tiny["vae"], tiny["clip"], frames, torch.from_numpy(nl), torch.from_numpy(na), steps=1, chunk=8)
-    assert np.abs(res.frames[0] - ref).max() < 3e-2
+    assert_abs(res.frames[0], ref, 1.5e-2, "tiny pipeline, 64 frames")
     big = rng.uniform(0, 1, (65, H, W, 3)).astype(np.float32)
     nl2, na2 = make_noise(65, H, W, seed=1)
     with pytest.raises((RuntimeError, ValueError, NotImplementedError)):
@@ -186,8 +194,8 @@ def test_latent_sliding_windows(tiny, T, window, overlap, steps):
     res = tiny["pipe"](frames, num_inference_steps=steps, window_size=window, overlap=overlap, noise_latents=nl, noise_aug=na)
     ref = run_pipeline(tiny["unet"], tiny["vae"], tiny["clip"], frames, torch.from_numpy(nl), torch.from_numpy(na), steps=steps, chunk=8,
                        window=window, overlap=overlap)
-    assert res.frames[0].shape == ref.shape and np.isfinite(res.frames[0]).all()
-    assert np.abs(res.frames[0] - ref).max() < 3e-2, np.abs(res.frames[0] - ref).max()
+    assert res.frames[0].shape == ref.shape
+    assert_abs(res.frames[0], ref, 1.4e-2, f"latent sliding windows T={T} window={window} overlap={overlap}")
     plain = tiny["pipe"](frames, num_inference_steps=steps, window_size=T, noise_latents=nl, noise_aug=na).frames[0]
     same = tiny["pipe"](frames, num_inference_steps=steps, window_size=T + 5, overlap=overlap, noise_latents=nl, noise_aug=na).frames[0]
     assert np.array_equal(plain, same)
@@ -214,14 +222,14 @@ def test_full_architecture_unet_and_vae_decoder_small_clip():
         with torch.no_grad():
             ref = unet(torch.from_numpy(x)[None], torch.tensor(tstep), torch.from_numpy(emb)[None], torch.tensor([[7.0, 127.0, 0.02]]))[0].numpy()
         del unet
-        assert_close(got, ref, 2e-2, "full-architecture UNet forward")
+        assert_close(got, ref, 3.5e-3, "full-architecture UNet forward")
         z = h16(rng.standard_normal((2, 4, 8, 8)) * 2)
         gotv = pipe.engine.vae_decode(z)
         vae = oracle_vae(v, sv)
         with torch.no_grad():
             fr = vae.decode(torch.from_numpy(z), 2)
             refv = (fr / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy()
-        assert np.abs(gotv - refv).max() < 2e-2, np.abs(gotv - refv).max()
+        assert_abs(gotv, refv, 4.5e-3, "full-architecture VAE decode (frames in [0,1])")
     finally:
         pipe.engine.close()
 
@@ -245,13 +253,24 @@ def test_full_architecture_clip_and_vae_encoder_small_clip():
             ref = clip(clip_preprocess(torch.from_numpy(frames).permute(0, 3, 1, 2) * 2.0 - 1.0)).numpy()
         del clip
         assert got.shape == ref.shape == (2, 1024)
-        assert_close(got, ref, 2e-2, "full-architecture CLIP image embedding")
+        assert_close(got, ref, 2.5e-3, "full-architecture CLIP image embedding")
         video = h16(rng.uniform(-1, 1, (2, 64, 64, 3)))
         gote = pipe.engine.vae_encode(video)
         vae = oracle_vae(v, sv)
         with torch.no_grad():
             refe = vae.encode_mode(torch.from_numpy(video).permute(0, 3, 1, 2)).numpy()
-        assert_close(gote, refe, 2e-2, "full-architecture VAE encode (posterior mode)")
+        assert_close(gote, refe, 1e-3, "full-architecture VAE encode, float32-grade (posterior mode, fp16 output)")
+        pipe.engine.set_vae_encode_fp32(False)
+        gote16 = pipe.engine.vae_encode(video)
+        pipe.engine.set_vae_encode_fp32(True)
+        assert_close(gote16, refe, 3e-3, "full-architecture VAE encode, fp16 storage")
+        # full frame size of BASELINE configs[1] (one 384x512 frame: S = 3072 mid-block attention, 196608-pixel level 0)
+        yy, xx = np.mgrid[0:384, 0:512].astype(np.float32)
+        big = h16(np.stack([np.sin(xx / 31.0 + c) * np.cos(yy / 23.0) * 0.8 + 0.1 * rng.standard_normal((384, 512)) for c in range(3)], -1)[None])
+        gotb = pipe.engine.vae_encode(big)
+        with torch.no_grad():
+            refb = vae.encode_mode(torch.from_numpy(big).permute(0, 3, 1, 2)).numpy()
+        assert_close(gotb, refb, 1e-3, "full-size (384x512) full-architecture VAE encode, float32-grade")
     finally:
         pipe.engine.close()
 
@@ -274,9 +293,7 @@ def test_full_architecture_pipeline_end_to_end():
         res = pipe(frames, num_inference_steps=2, window_size=T, noise_latents=nl, noise_aug=na)
         ref = run_pipeline(oracle_unet(u, su), oracle_vae(v, sv), oracle_clip(c, sc), frames, torch.from_numpy(nl), torch.from_numpy(na),
                            steps=2, chunk=8)
-        err = np.abs(res.frames[0] - ref).max()
-        print(f"full-architecture pipeline: max |HIP - oracle| = {err:.3e} on frames in [0,1]")
-        assert res.frames[0].shape == ref.shape and np.isfinite(res.frames[0]).all()
-        assert err < 3e-2, err
+        assert res.frames[0].shape == ref.shape
+        assert_abs(res.frames[0], ref, 6.5e-3, "full-architecture pipeline, 2 frames 64x64, 2 steps (frames in [0,1])")
     finally:
         pipe.engine.close()

@@ -14,7 +14,7 @@ world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCA
 if world > 1:
     torch.cuda.set_device(local)
     dist.init_process_group("nccl")
-ds = import_class_from_module("unigeo_amd.harness.dataset", cfg["dataset"])(**parse_dataset_config(cfg))
+ds = import_class_from_module("unigeo_amd.harness", cfg["dataset"])(**parse_dataset_config(cfg))
 model = import_class_from_module("unigeo_amd.model", cfg["model_name"])(device_id=local, **cfg["model_params"])
 rows, mm = evaluate_sharded(cfg, ds, model, dist=dist if world > 1 else None, verbose=(local == 0))
 if world > 1:

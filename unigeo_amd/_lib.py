@@ -18,7 +18,7 @@ EXPORTS = [
     "ug_unet_config_default", "ug_vae_config_default", "ug_clip_config_default",
     "ug_create", "ug_destroy", "ug_last_error", "ug_workspace_peak",
     "ug_load_tensor", "ug_bind_unet", "ug_bind_vae", "ug_bind_clip",
-    "ug_dc_set_inputs", "ug_dc_run", "ug_dc_run_windows", "ug_dc_get_outputs", "ug_dc_device_ptrs",
+    "ug_dc_set_inputs", "ug_dc_run", "ug_dc_run_windows", "ug_dc_get_outputs", "ug_dc_device_ptrs", "ug_dc_set_trace", "ug_set_vae_encode_fp32",
     "ug_eval_depth", "ug_eval_normal", "ug_clip_embed", "ug_vae_encode", "ug_vae_decode", "ug_unet_forward", "ug_normals_from_depth",
     "ug_op_linear", "ug_op_conv", "ug_op_groupnorm", "ug_op_layernorm", "ug_op_flash_attn",
     "ug_op_temporal_attn", "ug_op_attention_generic", "ug_op_euler_step",
@@ -78,6 +78,8 @@ def load_library():
     lib.ug_dc_run.argtypes = [vp, ip, ip, ip]
     lib.ug_dc_run_windows.argtypes = [vp, ip, ip, ip, ip, ip]
     lib.ug_dc_get_outputs.argtypes = [vp, vp, vp, vp]
+    lib.ug_dc_set_trace.argtypes = [vp, vp, ip]
+    lib.ug_set_vae_encode_fp32.argtypes = [vp, ip]
     lib.ug_dc_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.ug_eval_depth.argtypes = [vp, vp, vp, vp, C.c_long, C.c_float, vp]
     lib.ug_eval_normal.argtypes = [vp, vp, vp, vp, C.c_long, vp]
@@ -205,6 +207,21 @@ class Engine:
             self._ck(self.lib.ug_dc_run_windows(self.ctx, int(steps), int(decode_chunk), int(bool(with_normals)), int(window), int(overlap)))
         else:
             self._ck(self.lib.ug_dc_run(self.ctx, int(steps), int(decode_chunk), int(bool(with_normals))))
+
+    def set_vae_encode_fp32(self, on=True):
+        """True (default) = the reference's float32 VAE encoder (force_upcast); False = fp16 storage like the decoder."""
+        self._ck(self.lib.ug_set_vae_encode_fp32(self.ctx, int(bool(on))))
+
+    def run_traced(self, steps, decode_chunk=8, with_normals=False):
+        """ug_dc_run with the latents after every Euler step copied out: returns [steps, T, 4, h, w] float32."""
+        T, H, W = self._shape
+        tr = np.zeros((int(steps), T, H // 8, W // 8, 4), np.float32)
+        self._ck(self.lib.ug_dc_set_trace(self.ctx, _ptr(tr), int(steps)))
+        try:
+            self.run(steps, decode_chunk, with_normals)
+        finally:
+            self.lib.ug_dc_set_trace(self.ctx, None, 0)
+        return tr.transpose(0, 1, 4, 2, 3)
 
     def get_outputs(self, frames=True, depth=True, normals=False):
         T, H, W = self._shape

@@ -121,6 +121,16 @@ int ug_dc_run(ug_ctx* x, int steps, int chunk, int with_normals) { UG_TRY(x, dc_
 int ug_dc_run_windows(ug_ctx* x, int steps, int chunk, int with_normals, int window, int overlap) {
   UG_TRY(x, dc_run(x->c, steps, chunk, with_normals, window, overlap));
 }
+int ug_set_vae_encode_fp32(ug_ctx* x, int on) {
+  if (!x) return -1;
+  x->c.vae_encode_fp32 = on ? 1 : 0;
+  return 0;
+}
+int ug_dc_set_trace(ug_ctx* x, float* host_latents, int steps) {
+  if (!x) return -1;
+  x->c.trace_host = host_latents; x->c.trace_steps = host_latents ? steps : 0;
+  return 0;
+}
 int ug_dc_get_outputs(ug_ctx* x, float* f, float* d, float* n) { UG_TRY(x, dc_get_outputs(x->c, f, d, n)); }
 
 int ug_dc_device_ptrs(ug_ctx* x, void** f, void** d, void** n) {
@@ -273,8 +283,14 @@ int ug_eval_depth(ug_ctx* x, const float* pred, const float* gt, const unsigned 
     for (int b = 0; b < nb; ++b) for (int k = 0; k < 5; ++k) a[k] += h[b * 5 + k];
     // least squares of g ~ s*p + t:  [sum p^2, sum p; sum p, n] [s; t] = [sum pg; sum g]
     const double det = a[2] * a[0] - a[1] * a[1];
-    UG_REQUIRE(a[0] >= 2 && fabs(det) > 0, "degenerate depth alignment (fewer than 2 valid pixels or constant prediction)");
-    const double s_ = (a[4] * a[0] - a[1] * a[3]) / det, t_ = (a[2] * a[3] - a[1] * a[4]) / det;
+    // Degenerate clips do not abort the evaluation run (the reference's np.linalg.lstsq returns the minimum-norm solution
+    // and its loop continues, metrics/alignment.py:150-167): no valid pixel -> s = t = 0 and zero metrics below; rank-1
+    // system (one pixel / constant prediction p = c) -> [s, t] = mean(g) / (c^2 + 1) * [c, 1].
+    double s_ = 0.0, t_ = 0.0;
+    if (a[0] >= 1) {
+      if (fabs(det) > 1e-12 * fmax(1.0, a[2] * a[0])) { s_ = (a[4] * a[0] - a[1] * a[3]) / det; t_ = (a[2] * a[3] - a[1] * a[4]) / det; }
+      else { const double cm = a[1] / a[0], gm = a[3] / a[0]; s_ = cm * gm / (cm * cm + 1.0); t_ = gm / (cm * cm + 1.0); }
+    }
     launch_depth_metrics(dp, dg, dm, n, max_depth, (float)s_, (float)t_, part, &nb, c.stream);
     UG_CHECK(hipStreamSynchronize(c.stream));
     UG_CHECK(hipMemcpy(h.data(), part, (size_t)nb * 9 * 8, hipMemcpyDeviceToHost));
@@ -312,7 +328,10 @@ int ug_eval_normal(ug_ctx* x, const float* pred, const float* gt, const unsigned
     double m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int b = 0; b < nb; ++b) for (int k = 0; k < 8; ++k) m[k] += h[b * 8 + k];
     const long cnt = (long)m[0];
-    UG_REQUIRE(cnt > 0, "normal evaluation: empty mask");
+    if (cnt <= 0) {   // empty mask: NaN metrics like the reference's mean over an empty selection; MetricsManager skips NaN
+      for (int k = 0; k < 8; ++k) out[k] = NAN;
+      return 0;
+    }
     // torch.median = lower median = element (cnt-1)/2 of the sorted errors: find its bin, then sort that bin only
     const long kth = (cnt - 1) / 2;
     long acc = 0; int bin = 0;

@@ -166,6 +166,19 @@ void launch_normals(const float* depth, const float* K33, float* normals, int T,
                     hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
+// fp32-grade path over fp16 hi/lo pairs (kernels/wide.hip): the VAE encoder, which the reference runs in float32
+// ---------------------------------------------------------------------------------------
+void launch_split_pair(const float* x, f16* y, long M, int C, hipStream_t s);          // [M,C] f32 -> [M,2C] = [hi | lo]
+void launch_add_f32(const float* a, const float* b, float* y, long n, hipStream_t s);
+void launch_take_cols_f16(const float* x, long ldx, f16* y, long M, int C, hipStream_t s);
+size_t gn32_ws_bytes(int T, int HW, int C, int G);
+void launch_gn32_pair(const float* X, f16* Y, int T, int HW, int C, int G, float eps, int silu, const f16* gamma, const f16* beta,
+                      void* ws, hipStream_t s);                                          // GroupNorm(+SiLU) f32 -> pair
+void launch_qk_terms(const float* qkv, f16* Aq, f16* Bk, long M, int C, hipStream_t s);
+void launch_vt_terms(const float* qkv, f16* Vt, int B, int S, int Spad, int C, hipStream_t s);
+void launch_softmax_pair(const float* in, long ld_in, f16* out, int Spad, long rows, int S, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
 // Evaluation metrics on device (kernels/metrics.hip)
 // ---------------------------------------------------------------------------------------
 void launch_depth_fit(const float* pred, const float* gt, long n, float max_depth, double* part, int* nb, hipStream_t s);

@@ -77,6 +77,9 @@ struct VAE {
   Conv e_in, e_out, quant; Norm e_norm;
   struct EDown { std::vector<Res2D> res; Conv down; bool has_down = false; };
   std::vector<EDown> edown; Res2D emid0, emid1; VAttn eattn;
+  // the same encoder with K-doubled weights [W | W] for fp16 hi/lo-pair activations (kernels/wide.hip): the reference runs
+  // the encoder in float32 (force_upcast); norms share gamma / beta with the fp16 structures above
+  std::vector<EDown> edown_w; Res2D emid0_w, emid1_w; VAttn eattn_w; Conv e_out_w, quant_w; bool wide_bound = false;
   Conv d_in, d_out; Norm d_norm; const f16* tco_w = nullptr; const f16* tco_b = nullptr;
   std::vector<STRes> dmid; VAttn dattn;
   struct DUp { std::vector<STRes> res; Conv up; bool has_up = false; };
@@ -109,6 +112,9 @@ struct Ctx {
   float* d_out_frames = nullptr; float* d_depth = nullptr; float* d_normals = nullptr; float* d_mm = nullptr;
   f16* d_clip_emb = nullptr; f16* d_cond = nullptr; f16* d_lat = nullptr;
   size_t io_mark = 0; bool io_ready = false;
+  // parity instrumentation: when set, dc_run copies the latents after every Euler step to this host buffer ([steps][T*h*w*4] f32)
+  float* trace_host = nullptr; int trace_steps = 0;
+  int vae_encode_fp32 = 1;   // 1 = reference behaviour (float32-grade encoder), 0 = fp16 storage like the decoder
 };
 
 // ---- binding ----
@@ -122,7 +128,7 @@ void finish_binding(Ctx& c, const std::string& prefix);   // fail on unused tens
 // x [T,h,w,in_ch] f16; clip_emb [T,cross_dim] f16; tsteps host array of continuous timesteps
 void unet_prepare(Ctx& c, int T, const f16* clip_emb, const float* timesteps, int nsteps);
 f16* unet_forward(Ctx& c, const f16* x, int T, int h, int w, int step);   // -> [T,h,w,out_ch] (ws)
-f16* vae_encode(Ctx& c, const f16* x8, int T, int H, int W);              // x8 [T,H,W,8] -> [T,H/8,W/8,4]
+f16* vae_encode(Ctx& c, const f16* x8, int T, int H, int W);              // x8 [T,H,W,8] -> [T,H/8,W/8,4]; precision per c.vae_encode_fp32
 void vae_decode(Ctx& c, const f16* z, int T, int h, int w, float* frames_out);  // z [T,h,w,4] (already /scaling) -> f32 [T,8h,8w,3]
 f16* clip_embed(Ctx& c, const f16* video_m11, int T, int H, int W);       // [T,H,W,3] -> [T,proj]
 

@@ -305,6 +305,31 @@ static Conv bind_conv(Ctx& c, const std::string& p, int cin, int cout, int kt, i
   return cv;
 }
 
+// K-doubled copies for fp16 hi/lo-pair activations (kernels/wide.hip): [O][taps][Cinp] -> [O][taps][Cinp | Cinp], [N][K] -> [N][K | K]
+static Conv dup_conv(Ctx& c, const Conv& cv) {
+  Conv d = cv; d.wphase = nullptr;
+  const long rows = (long)cv.cout * cv.kt * cv.ky * cv.kx;
+  f16* w = c.persist.get<f16>(rows * 2 * cv.cinp);
+  launch_copy2d(cv.w, cv.cinp, w, 2 * cv.cinp, rows, cv.cinp, c.stream);
+  launch_copy2d(cv.w, cv.cinp, w + cv.cinp, 2 * cv.cinp, rows, cv.cinp, c.stream);
+  d.w = w; d.cin = 2 * cv.cinp; d.cinp = 2 * cv.cinp;
+  return d;
+}
+static Lin dup_lin(Ctx& c, const Lin& l) {
+  Lin d = l;
+  f16* w = c.persist.get<f16>((long)l.out * 2 * l.in);
+  launch_copy2d(l.w, l.in, w, 2 * l.in, l.out, l.in, c.stream);
+  launch_copy2d(l.w, l.in, w + l.in, 2 * l.in, l.out, l.in, c.stream);
+  d.w = w; d.in = 2 * l.in;
+  return d;
+}
+static Res2D dup_res2d(Ctx& c, const Res2D& r) {
+  Res2D d = r;
+  d.c1 = dup_conv(c, r.c1); d.c2 = dup_conv(c, r.c2);
+  if (r.has_sc) d.sc = dup_conv(c, r.sc);
+  return d;
+}
+
 static Res2D bind_res2d(Ctx& c, const std::string& p, int cin, int cout, int temb, float eps) {
   Res2D r;
   r.n1 = bind_norm(c, p + ".norm1", cin, eps);
@@ -486,6 +511,18 @@ void bind_vae(Ctx& c, const VAECfg& cfg, const std::string& pre) {
   UG_REQUIRE(cfg.out_ch == 3, "time_conv_out kernel is written for 3 output channels");
   v.tco_w = persist_f16(c, raw_get(c, pre + "decoder.time_conv_out.weight", {3, 3, 3, 1, 1}));
   v.tco_b = persist_f16(c, raw_get(c, pre + "decoder.time_conv_out.bias", {3}));
+  // float32-grade encoder (reference: force_upcast): K-doubled weights, +2x the encoder's 34 M parameters
+  v.edown_w.resize(n);
+  for (int i = 0; i < n; ++i) {
+    for (auto& r : v.edown[i].res) v.edown_w[i].res.push_back(dup_res2d(c, r));
+    v.edown_w[i].has_down = v.edown[i].has_down;
+    if (v.edown[i].has_down) v.edown_w[i].down = dup_conv(c, v.edown[i].down);
+  }
+  v.emid0_w = dup_res2d(c, v.emid0); v.emid1_w = dup_res2d(c, v.emid1);
+  v.eattn_w = v.eattn; v.eattn_w.qkv = dup_lin(c, v.eattn.qkv); v.eattn_w.out = dup_lin(c, v.eattn.out);
+  v.e_out_w = dup_conv(c, v.e_out); v.quant_w = dup_conv(c, v.quant);
+  UG_CHECK(hipStreamSynchronize(c.stream));
+  v.wide_bound = true;
   v.bound = true;
 }
 
@@ -840,7 +877,133 @@ static f16* vattn_forward(Ctx& c, const VAttn& at, const f16* x, int T, int hw, 
   return out;
 }
 
+// ---- float32-grade encoder: fp32 residual stream / norms / softmax, GEMMs on fp16 hi/lo pairs (kernels/wide.hip) ----
+static void gn32(Ctx& c, const float* x, int T, int HW, int G, const Norm& n, int silu, f16* ypair) {
+  const size_t mk = c.ws.mark();
+  void* ws = c.ws.alloc(gn32_ws_bytes(T, HW, n.c, G));
+  {
+    ProfScope ps(c, "groupnorm_f32", 0, (double)T * HW * n.c * 12.0);
+    launch_gn32_pair(x, ypair, T, HW, n.c, G, n.eps, silu, n.g, n.b, ws, c.stream);
+  }
+  c.ws.release(mk);
+}
+static void split_pair(Ctx& c, const float* x, f16* y, long M, int C) {
+  ProfScope ps(c, "split_pair", 0, (double)M * C * 8.0);
+  launch_split_pair(x, y, M, C, c.stream);
+}
+static void add_f32(Ctx& c, const float* a, const float* b, float* y, long n) {
+  ProfScope ps(c, "add_f32", 0, (double)n * 12.0);
+  launch_add_f32(a, b, y, n, c.stream);
+}
+// conv over a pair tensor [M, 2C] with K-doubled weights -> fp32 [M, cout]
+static void conv_w(Ctx& c, const f16* xpair, int T, int Hi, int Wi, const Conv& cv, int stride, int pad_t, int pad_l, float* out) {
+  Epi e; e.flags = UG_F_OUT_F32;
+  conv(c, xpair, cv.cinp, nullptr, 0, T, Hi, Wi, cv, stride, pad_t, pad_l, 1, (f16*)out, e);
+}
+static void res2d_wide(Ctx& c, const Res2D& r, const float* x, int cin, int T, int h, int w, int G, float* out) {
+  const long M = (long)T * h * w;
+  const int cout = r.c1.cout;
+  const size_t mk = c.ws.mark();
+  f16* a = c.ws.get<f16>(M * 2 * std::max(cin, cout));
+  gn32(c, x, T, h * w, G, r.n1, 1, a);
+  float* hb = c.ws.get<float>(M * cout);
+  conv_w(c, a, T, h, w, r.c1, 1, 1, 1, hb);
+  gn32(c, hb, T, h * w, G, r.n2, 1, a);           // `a` is dead after conv1 (stream order)
+  conv_w(c, a, T, h, w, r.c2, 1, 1, 1, hb);        // hb is dead after the second GroupNorm
+  const float* res = x;
+  if (r.has_sc) {
+    split_pair(c, x, a, M, cin);
+    conv_w(c, a, T, h, w, r.sc, 1, 0, 0, out);
+    res = out;
+  }
+  add_f32(c, hb, res, out, M * cout);
+  c.ws.release(mk);
+}
+static void vattn_wide(Ctx& c, const VAttn& at, const float* x, int T, int hw, int G, float* out) {
+  const int C = at.C, S = hw, Spad = pad8(S); const long M = (long)T * hw;
+  const size_t mk = c.ws.mark();
+  f16* xn = c.ws.get<f16>(M * 2 * C);
+  gn32(c, x, T, hw, G, at.gn, 0, xn);
+  float* qkv = c.ws.get<float>(M * 3 * C);
+  { Epi e; e.flags = UG_F_OUT_F32; linear(c, xn, M, at.qkv, (f16*)qkv, e); }
+  f16* Aq = c.ws.get<f16>(M * 3 * C); f16* Bk = c.ws.get<f16>(M * 3 * C);
+  launch_qk_terms(qkv, Aq, Bk, M, C, c.stream);
+  f16* Vt = c.ws.get<f16>((long)T * C * 3 * Spad);
+  launch_vt_terms(qkv, Vt, T, S, Spad, C, c.stream);
+  float* sc = c.ws.get<float>((long)T * S * Spad);
+  GemmP p; memset(&p, 0, sizeof(p));
+  p.A0 = Aq; p.C0 = 3 * C; p.M = S; p.N = S; p.K = 3 * C; p.W = Bk; p.ldw = 3 * C;
+  p.c0 = 1.0f / sqrtf((float)C); p.Out = sc; p.ldo = Spad; p.flags = UG_F_OUT_F32;
+  p.nb_inner = 1; p.sA_o = (long)S * 3 * C; p.sW_o = (long)S * 3 * C; p.sO_o = (long)S * Spad;
+  run_gemm(c, p, T, "gemm_attn_qk");
+  f16* P = c.ws.get<f16>((long)T * S * 3 * Spad);
+  {
+    ProfScope ps(c, "softmax_rows", 0, (double)T * S * Spad * 10.0);
+    launch_softmax_pair(sc, Spad, P, Spad, (long)T * S, S, c.stream);
+  }
+  float* ao = qkv;   // qkv is dead (Aq / Bk / Vt hold its terms)
+  GemmP q; memset(&q, 0, sizeof(q));
+  q.A0 = P; q.C0 = 3 * Spad; q.M = S; q.N = C; q.K = 3 * Spad; q.W = Vt; q.ldw = 3 * Spad; q.c0 = 1.f;
+  q.Out = ao; q.ldo = C; q.flags = UG_F_OUT_F32; q.nb_inner = 1;
+  q.sA_o = (long)S * 3 * Spad; q.sW_o = (long)C * 3 * Spad; q.sO_o = (long)S * C;
+  run_gemm(c, q, T, "gemm_attn_pv");
+  split_pair(c, ao, xn, M, C);
+  float* o = c.ws.get<float>(M * C);
+  { Epi e; e.flags = UG_F_OUT_F32; linear(c, xn, M, at.out, (f16*)o, e); }
+  add_f32(c, o, x, out, M * C);
+  c.ws.release(mk);
+}
+
+static f16* vae_encode_wide(Ctx& c, const f16* x8, int T, int H, int W) {
+  VAE& v = c.vae;
+  UG_REQUIRE(v.wide_bound, "float32-grade VAE encoder weights are not bound");
+  const VAECfg& cfg = v.cfg; const int G = cfg.groups, n = cfg.nlev;
+  int hh = H, ww = W;
+  for (int i = 0; i < n - 1; ++i) { hh /= 2; ww /= 2; }
+  f16* lat = c.ws.get<f16>((long)T * hh * ww * cfg.lat);
+  const size_t mk = c.ws.mark();
+  int ch = cfg.boc[0], ch_h = H, ch_w = W;
+  float* cur = c.ws.get<float>((long)T * H * W * ch);
+  { Epi e; e.flags = UG_F_OUT_F32; conv(c, x8, 8, nullptr, 0, T, H, W, v.e_in, 1, 1, 1, 1, (f16*)cur, e); }   // fp16 image: exact as is
+  for (int i = 0; i < n; ++i) {
+    for (auto& r : v.edown_w[i].res) {
+      float* o = c.ws.get<float>((long)T * ch_h * ch_w * r.c1.cout);
+      res2d_wide(c, r, cur, ch, T, ch_h, ch_w, G, o);
+      cur = o; ch = r.c1.cout;
+    }
+    if (v.edown_w[i].has_down) {   // F.pad(0,1,0,1) + stride-2 conv without padding
+      const long Mi = (long)T * ch_h * ch_w;
+      float* d = c.ws.get<float>(Mi / 4 * ch);
+      const size_t m2 = c.ws.mark();
+      f16* xp = c.ws.get<f16>(Mi * 2 * ch);
+      split_pair(c, cur, xp, Mi, ch);
+      conv_w(c, xp, T, ch_h, ch_w, v.edown_w[i].down, 2, 0, 0, d);
+      c.ws.release(m2);
+      ch_h /= 2; ch_w /= 2; cur = d;
+    }
+  }
+  const long M = (long)T * ch_h * ch_w;
+  float* o = c.ws.get<float>(M * ch);
+  res2d_wide(c, v.emid0_w, cur, ch, T, ch_h, ch_w, G, o); cur = o;
+  o = c.ws.get<float>(M * ch);
+  vattn_wide(c, v.eattn_w, cur, T, ch_h * ch_w, G, o); cur = o;
+  o = c.ws.get<float>(M * ch);
+  res2d_wide(c, v.emid1_w, cur, ch, T, ch_h, ch_w, G, o); cur = o;
+  f16* a = c.ws.get<f16>(M * 2 * ch);
+  gn32(c, cur, T, ch_h * ch_w, G, v.e_norm, 1, a);
+  float* mom = c.ws.get<float>(M * 2 * cfg.lat);
+  conv_w(c, a, T, ch_h, ch_w, v.e_out_w, 1, 1, 1, mom);
+  f16* mp = c.ws.get<f16>(M * 4 * cfg.lat);
+  split_pair(c, mom, mp, M, 2 * cfg.lat);
+  float* q = c.ws.get<float>(M * 2 * cfg.lat);
+  conv_w(c, mp, T, ch_h, ch_w, v.quant_w, 1, 0, 0, q);
+  launch_take_cols_f16(q, 2 * cfg.lat, lat, M, cfg.lat, c.stream);   // latent_dist.mode() = mean half, cast to the pipeline's fp16
+  c.ws.release(mk);
+  return lat;
+}
+
 f16* vae_encode(Ctx& c, const f16* x8, int T, int H, int W) {
+  if (c.vae_encode_fp32) return vae_encode_wide(c, x8, T, H, W);
   VAE& v = c.vae;
   UG_REQUIRE(v.bound, "VAE weights are not bound");
   const VAECfg& cfg = v.cfg; const int G = cfg.groups;
@@ -1045,6 +1208,12 @@ void dc_run(Ctx& c, int steps, int chunk, int with_normals, int window, int over
       launch_make_unet_input(lat, cond, xin, lp, sqrtf(sig[i] * sig[i] + 1.f), c.stream);
       f16* v = unet_forward(c, xin, T, h, w, i);
       launch_euler_step(v, lat, lp * 4, sig[i], sig[i + 1], c.stream);
+      if (c.trace_host && i < c.trace_steps) {   // parity instrumentation only (tests/): latents [T,h,w,4] after step i
+        float* tf = c.ws.get<float>(lp * 4);
+        launch_cast_f16_f32(lat, tf, lp * 4, c.stream);
+        UG_CHECK(hipMemcpyAsync(c.trace_host + (size_t)i * lp * 4, tf, (size_t)lp * 4 * 4, hipMemcpyDeviceToHost, c.stream));
+        UG_CHECK(hipStreamSynchronize(c.stream));
+      }
       c.ws.release(m2);
     }
   } else {

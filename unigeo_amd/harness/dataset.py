@@ -58,5 +58,5 @@ class SyntheticGeometryDataset:
         return {"scene_name": "synthetic", "images": [f["image"] for f in fr], "intrinsics": [f["K"] for f in fr],
                 "extrinsics": [f["ext"] for f in fr], "cam_coord": [f["cam"] for f in fr],
                 "cam_normal": [f["normal"] for f in fr], "world_coord": [f["world"] for f in fr],
-                "mask": [f["mask"] for f in fr], "keyview_idx": 0,
+                "mask": [f["mask"] for f in fr], "keyview_idx": 0, "_index": i,
                 "image_names": [f"frame-{t:06d}.color.png" for t in self.clips[i]]}

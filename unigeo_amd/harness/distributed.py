@@ -22,7 +22,7 @@ def evaluate_sharded(config, dataset, model, save_dir="./debug_output", dist=Non
         gathered = [None] * world
         dist.all_gather_object(gathered, rows)
         rows = [r for part in gathered for r in part]
-    rows.sort(key=lambda r: r["seq_name"])          # "%03d_scene": dataset order
+    rows.sort(key=lambda r: int(r["seq_name"].split("_", 1)[0]))   # "<data_idx>_<scene>": dataset order (numeric: >= 1000 clips)
     mm = MetricsManager(metric_names=parse_metric_config(config))
     for r in rows:
         mm.update_metrics(r)

@@ -16,9 +16,13 @@ def import_class_from_module(module_name, class_name):
 
 
 def parse_dataset_config(config):
-    return {"root": config["root"], "clip_length": config.get("clip_length", 30),
-            "clip_overlap": config.get("clip_overlap", 0), "input_size": (config["h"], config["w"]),
-            "target_size": (config["h"], config["w"])}
+    out = {"root": config["root"], "clip_length": config.get("clip_length", 30),
+           "clip_overlap": config.get("clip_overlap", 0), "input_size": (config["h"], config["w"]),
+           "target_size": (config["h"], config["w"])}
+    for k in ("split", "split_file", "scenes"):      # optional: which scene list the loader walks (default: the split file)
+        if k in config:
+            out[k] = config[k]
+    return out
 
 
 def parse_metric_config(config):

@@ -64,6 +64,9 @@ def normal_evaluation(predicted_normal_original, ground_truth_normal_original, c
     err = np.degrees(np.arccos(np.clip(cosang, -1.0, 1.0))).astype(np.float32)
     e = err[_np(custom_mask).astype(bool)] if custom_mask is not None else err.reshape(-1)
     n = e.size
+    if n == 0:   # empty mask: NaN metrics (the reference's mean over an empty selection); MetricsManager skips NaN rows
+        return {k: float("nan") for k in ("normal mean", "normal median", "normal rmse", "angle < 5", "angle < 7.5",
+                                          "angle < 11.25", "angle < 22.5", "angle < 30")}
     out = {"normal mean": float(e.mean(dtype=np.float32)), "normal median": float(np.sort(e)[(n - 1) // 2]),
            "normal rmse": float(np.sqrt((e * e).sum(dtype=np.float32) / n))}
     for k in (5, 7.5, 11.25, 22.5, 30):

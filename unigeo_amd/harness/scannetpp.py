@@ -18,7 +18,7 @@ depth/*.png}``):
 Pinned by ``tests/golden/scannetpp_golden.npz`` (outputs of the reference's own classes on the synthetic scene in
 ``tests/golden/scannetpp_scene``).  The resize step follows scikit-image's published ``transform.resize`` recipe
 (gaussian pre-filter sigma=(s-1)/2 when down-scaling, ``scipy.ndimage.zoom(grid_mode=True, mode='mirror')``) through
-scipy; scikit-image itself is not installed here, so that step is NOT golden-pinned.
+scipy; scikit-image itself is not installed here, so that step is UNPINNED (native-size loads are bit-exact vs the reference).
 """
 import os
 
@@ -87,12 +87,21 @@ class ScannetPPDataset:
                  input_size=None, target_size=None, verbose=False, **_):
         if root is None or not os.path.isdir(root):
             raise FileNotFoundError(f"ScanNet++ root not found: {root!r}")
-        if scenes is None:
-            if split_file is not None:                      # scannetpp.py:213-217 reads splits/<split>.txt
-                with open(split_file) as f:
-                    scenes = f.read().splitlines()
-            else:
-                scenes = sorted(d for d in os.listdir(root) if os.path.isfile(os.path.join(root, d, "scene_metadata.npz")))
+        if isinstance(scenes, str):
+            if scenes != "all":
+                raise ValueError('scenes must be a list of scene names, None (the split list) or "all"')
+            # explicit opt-in: every processed scene under root, sorted (NOT what the reference evaluates)
+            scenes = sorted(d for d in os.listdir(root) if os.path.isfile(os.path.join(root, d, "scene_metadata.npz")))
+        elif scenes is None:
+            # scannetpp.py:209-217: the scene set and its ORDER come from splits/<split>.txt next to the loader
+            # ('train' or, for every other split value, 'nvs_sem_val' - the ten validation scenes, shipped as data)
+            if split_file is None:
+                split_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "splits",
+                                          ("train" if split == "train" else "nvs_sem_val") + ".txt")
+            if not os.path.isfile(split_file):
+                raise FileNotFoundError(f"ScanNet++ split list not found: {split_file} (pass split_file=... or scenes=[...])")
+            with open(split_file) as f:
+                scenes = [ln for ln in f.read().splitlines() if ln.strip()]
         self.root, self.split = root, split
         self.input_size, self.target_size = input_size, target_size
         self.samples = []

@@ -8,7 +8,8 @@ Mirrors ``/root/reference/model/depthcrafter.py`` member for member:
 Differences that are deliberate and visible:
   * the denoise loop, VAE, CLIP, the depth post-processing AND the back-projection / surface-normal
     step (40 s per clip on the reference's CPU path) run on the GPU inside one C-ABI call;
-  * noise comes from a seeded CPU generator (``seed`` kwarg) instead of the global CUDA RNG;
+  * noise comes from a seeded CPU generator (``seed`` kwarg + the sample's dataset index, so clips get independent noise
+    like the reference's fresh draws) instead of the un-seeded global CUDA RNG;
   * ``num_inference_steps`` defaults to the reference's shipped value 5 (:86) and is a kwarg;
   * without checkpoints on disk the constructor raises unless ``synthetic_weights=True`` is passed.
 """
@@ -23,6 +24,7 @@ class DepthCrafter:
     def __init__(self, model_dir=None, unet_path=None, pre_train_path=None, **kwargs):
         self.num_inference_steps = int(kwargs.get("num_inference_steps", 5))
         self.seed = int(kwargs.get("seed", 0))
+        self._calls = 0
         device_id = int(kwargs.get("device_id", 0))
         self.device = f"hip:{device_id}"
         print(f"Using device: {self.device}")
@@ -53,8 +55,12 @@ class DepthCrafter:
     def forward(self, data):
         frames = self.prepare_input(data)
         K = np.stack([np.asarray(k, dtype=np.float32).reshape(3, 3) for k in data["intrinsics"]], 0)
+        # the reference draws fresh noise per clip from the global RNG; here: a per-clip seed derived from the sample's
+        # dataset index (reproducible, rank-independent in sharded runs), or a call counter for anonymous samples
+        clip_seed = self.seed + int(data["_index"]) if "_index" in data else self.seed + self._calls
+        self._calls += 1
         res = self.pipeline(frames, height=frames.shape[1], width=frames.shape[2], output_type="np",
                             guidance_scale=1.0, num_inference_steps=self.num_inference_steps,
-                            window_size=len(frames), overlap=25, track_time=False, seed=self.seed,
+                            window_size=len(frames), overlap=25, track_time=False, seed=clip_seed,
                             intrinsics=K, with_normals=True)
         return self.prepare_output(res.depth, res.normals)
