@@ -27,37 +27,56 @@ TFLOP_UNET, TFLOP_VAE_ENC, TFLOP_VAE_DEC, TFLOP_CLIP = 23.21, 20.78, 56.89, 8.38
 PEAK_TFLOPS_F16 = 2500.0          # dense fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(threads):
-    """Oracle (torch-CPU fp32 restatement; diffusers is not installed) timed on a bounded sample:
-    one full-size SVD-UNet forward on 1 frame of 48x64 latents, on at most 32 host threads
-    (torch-CPU gets slower, not faster, beyond that on this op mix).  Rate -> frames/s via the
-    algorithmic FLOPs of a whole clip."""
+def cpu_baseline(threads, T=3, H=192, W=256, steps=2):
+    """BASELINE.md 4 / SURVEY.md 8d: the WHOLE pipeline of the CPU oracle (torch-CPU fp32 restatement; diffusers is not
+    installed, so kind = "port") - CLIP embed + float32 VAE encode + `steps` Euler steps of the 1.52 B-parameter UNet +
+    temporal VAE decode - timed per component on a bounded clip (T frames at HxW: ~5 TFLOP, 10-30 s of host work), then
+    extrapolated component by component with the algorithmic FLOPs to the 25-frame 384x512, 25-step clip of the metric
+    (per-frame work for CLIP; frames x pixels for the VAE and the UNet; the UNet term also x 25/steps)."""
     import torch
+    from oracle.clip import CLIPVisionWithProjection
+    from oracle.pipeline import run_pipeline
     from oracle.svd_unet import UNetSpatioTemporal
+    from oracle.vae import AutoencoderKLTemporalDecoder
+    from unigeo_amd.pipeline import make_noise
+    from unigeo_amd.synthetic import synthetic_clip
+    from unigeo_amd.model.depthcrafter import DepthCrafter
     torch.set_num_threads(threads)
-    with torch.device("meta"):
-        m = UNetSpatioTemporal()
-    m = m.to_empty(device="cpu")
     g = torch.Generator().manual_seed(0)
-    with torch.no_grad():
-        for p in m.parameters():
-            p.uniform_(-0.02, 0.02, generator=g)
-    m.eval()
-    Ts = 1
-    x = torch.randn(1, Ts, 8, 48, 64, generator=g)
-    emb = torch.randn(1, Ts, 1024, generator=g)
-    ids = torch.tensor([[7.0, 127.0, 0.02]])
-    with torch.no_grad():
-        t0 = time.time()
-        m(x, torch.tensor(0.5), emb, ids)
-        dt = time.time() - t0
-    tflop = TFLOP_UNET * Ts / 25.0
-    rate = tflop / dt                                     # TFLOP/s on the host cores
-    clip_tflop = 25 * TFLOP_UNET + TFLOP_VAE_ENC + TFLOP_VAE_DEC + TFLOP_CLIP
-    return {"value": 25.0 / (clip_tflop / rate), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"oracle SVD-UNet fp32 forward on {Ts} frames of 48x64 latents ({tflop:.2f} TFLOP) took {dt:.1f}s "
-                      f"= {rate * 1000:.0f} GFLOP/s; extrapolated by algorithmic FLOPs to one 25-frame/25-step clip "
-                      f"({clip_tflop:.1f} TFLOP)"}
+    t0 = time.time()
+    block = torch.empty(1 << 20).uniform_(-0.02, 0.02, generator=g)     # tiled into the 2.2 G parameters (a per-element RNG pass takes ~1 min)
+    mods = []
+    for cls in (UNetSpatioTemporal, AutoencoderKLTemporalDecoder, CLIPVisionWithProjection):
+        with torch.device("meta"):
+            m = cls()
+        m = m.to_empty(device="cpu")
+        with torch.no_grad():
+            for p in m.parameters():
+                flat, nb = p.view(-1), block.numel()
+                full = flat.numel() // nb
+                if full:
+                    flat[:full * nb].view(full, nb).copy_(block)
+                flat[full * nb:].copy_(block[:flat.numel() - full * nb])
+        mods.append(m.eval())
+    t_init = time.time() - t0
+    unet, vae, clip = mods
+    frames = DepthCrafter.prepare_input(None, synthetic_clip(T, H, W, seed=1234))
+    nl, na = make_noise(T, H, W, seed=0)
+    tm = {}
+    t0 = time.time()
+    run_pipeline(unet, vae, clip, frames, torch.from_numpy(nl), torch.from_numpy(na), steps=steps, timing=tm)
+    wall = time.time() - t0
+    frac = (T * H * W) / (25.0 * 384 * 512)
+    full = {"clip_s": tm["clip_s"] * 25.0 / T, "vae_encode_s": tm["vae_encode_s"] / frac,
+            "unet_s": tm["unet_s"] / frac * 25.0 / steps, "vae_decode_s": tm["vae_decode_s"] / frac}
+    full_s = sum(full.values())
+    tflop = TFLOP_CLIP * T / 25.0 + (TFLOP_VAE_ENC + TFLOP_VAE_DEC + steps * TFLOP_UNET) * frac
+    return {"value": 25.0 / full_s, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (torch-CPU fp32 restatement; diffusers unavailable) whole pipeline on a {T}-frame {H}x{W} clip, {steps} Euler steps "
+                      f"({tflop:.2f} TFLOP): {wall:.1f} s wall = {tflop / wall * 1000:.0f} GFLOP/s on {threads} threads; components extrapolated by algorithmic "
+                      f"work to the 25-frame 384x512 25-step clip ({full_s:.0f} s/clip)",
+            "sample_seconds": {k: round(v, 2) for k, v in tm.items()}, "sample_wall_s": round(wall, 2), "weight_init_s": round(t_init, 1),
+            "extrapolated_clip_seconds": {k: round(v, 1) for k, v in full.items()}}
 
 
 def main():
@@ -153,18 +172,42 @@ def main():
                                "launches": g_calls, "avg_launch_us": round(g_ms * 1000.0 / max(g_calls, 1), 2),
                                "algorithmic_tflop": round(g_fl / 1e12, 2),
                                "algorithmic_bytes_per_launch": round(sum(v.get("bytes", 0) for v in gem.values()) / max(g_calls, 1))}
-            try:   # HBM traffic of the same kernel family from the committed PMC passes (tools/pmc_traffic.sh)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_gemm.json")))
+            # HBM traffic of the same kernel family: rocprofv3 PMC passes collected by the committed script tools/pmc_traffic.sh
+            # (FETCH_SIZE and WRITE_SIZE in separate passes, counters only) -> profiles/r02_pmc_traffic_gemm.json, which
+            # also carries the algorithmic bytes of ITS OWN step mix; the file is cited by hash
+            try:
+                import hashlib
+                pf = os.path.join(ROOT, "profiles", "r02_pmc_traffic_gemm.json")
+                raw = open(pf, "rb").read()
+                pm = json.loads(raw)
                 res["roofline"]["traffic"] = round(pm["hbm_bytes_per_launch"])
-                res["roofline"]["traffic_note"] = ("bytes per GEMM-family launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes "
-                                                   "on a 3-step clip (profiles/r01_pmc_traffic_gemm.json), FETCH doubled per the gfx950 note; algorithmic bytes per launch of that "
-                                                   "3-step mix: 138 MB (this line's algorithmic_bytes_per_launch is the 25-step mix)")
+                res["roofline"]["traffic_source"] = {"file": "profiles/r02_pmc_traffic_gemm.json", "sha256": hashlib.sha256(raw).hexdigest(),
+                                                     "script": "tools/pmc_traffic.sh", "denoise_steps": pm.get("denoise_steps"),
+                                                     "algorithmic_bytes_per_launch_same_mix": pm.get("algorithmic_bytes_per_launch"),
+                                                     "traffic_over_algorithmic": pm.get("traffic_over_algorithmic"),
+                                                     "note": "bytes per GEMM-family launch; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md; "
+                                                             "Infinity-Cache hits are counted by these fabric-side counters"}
             except Exception:
                 pass
             res["kernel_ms"] = {k: round(v["ms"], 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
             if full:
                 clip_tflop = a.denoise_steps * TFLOP_UNET + TFLOP_VAE_ENC + TFLOP_VAE_DEC + TFLOP_CLIP
                 res["pipeline_tflops"] = round(clip_tflop / (ms * 1e-3), 1)
+        if full and not a.no_profile:
+            # also report the rate with prepare_output's normals inside the call, the reference-as-shipped N = 5 rate
+            # (model/depthcrafter.py:86) and the cost of the reference-faithful float32 VAE encoder vs the fp16-storage one
+            def rate(n, steps, **kw):
+                eng.run(steps, 8, **kw)
+                t1 = time.perf_counter()
+                for _ in range(n):
+                    eng.run(steps, 8, **kw)
+                return n * T / (time.perf_counter() - t1)
+            res["value_with_normals"] = round(rate(2, a.denoise_steps, with_normals=True), 3)
+            res["value_n5_steps"] = round(rate(3, 5, with_normals=False), 3)
+            eng.set_vae_encode_fp32(False)
+            res["value_fp16_vae_encoder"] = round(rate(2, a.denoise_steps, with_normals=False), 3)
+            eng.set_vae_encode_fp32(True)
+            res["vae_encoder"] = "float32-grade (reference force_upcast): fp32 residual stream / norms / softmax, fp16 hi/lo-pair MFMA GEMMs"
         res["workspace_peak_gb"] = round(eng.workspace_peak() / 2 ** 30, 2)
         if not a.no_cpu_baseline and world == 1:
             try:

@@ -30,7 +30,7 @@ def prepare_input(images):
 
 @torch.no_grad()
 def run_pipeline(unet, vae, clip, frames_thwc, noise_latents, noise_aug, steps,
-                 chunk=8, dtype=torch.float32, vae_encode_dtype=None, return_stages=False, window=None, overlap=0):
+                 chunk=8, dtype=torch.float32, vae_encode_dtype=None, return_stages=False, window=None, overlap=0, timing=None):
     """frames_thwc np/tensor [T,H,W,3] f32 in [0,1]; noise_latents [1,T,4,h,w];
     noise_aug [T,3,H,W] -> np [T,H,W,3] f32 in [0,1].
 
@@ -39,7 +39,15 @@ def run_pipeline(unet, vae, clip, frames_thwc, noise_latents, noise_aug, steps,
     PARITY UNPINNED: windows advance by window - overlap; a window after the first starts its first `overlap` frames from the
     previous result re-noised to sigma_0; the window's unit noise is the previous one rotated by `overlap` frames; the overlap is
     cross-faded with linspace(0, 1, overlap) into the running result.  The first `window` frames of noise_latents are the noise."""
+    import time
     st = {}
+    tick = [time.perf_counter()]
+
+    def lap(name):                      # component wall-clock for bench.py's cpu_baseline (timing = dict or None)
+        now = time.perf_counter()
+        if timing is not None:
+            timing[name] = timing.get(name, 0.0) + now - tick[0]
+        tick[0] = now
     video = torch.as_tensor(frames_thwc).permute(0, 3, 1, 2).to(dtype)
     video = video * 2.0 - 1.0
     T = video.shape[0]
@@ -49,6 +57,7 @@ def run_pipeline(unet, vae, clip, frames_thwc, noise_latents, noise_aug, steps,
         emb.append(clip(clip_preprocess(video[i:i + chunk]).to(dtype)))
     emb = torch.cat(emb, 0).unsqueeze(0)                       # [1,T,1024]
     st["clip_emb"] = emb
+    lap("clip_s")
     # noise augmentation + VAE encode (fp32 in the reference: force_upcast)
     video = video + NOISE_AUG * noise_aug.to(dtype)
     edt = vae_encode_dtype or torch.float32
@@ -58,6 +67,7 @@ def run_pipeline(unet, vae, clip, frames_thwc, noise_latents, noise_aug, steps,
     vae.to(dtype)
     cond = torch.cat(lat, 0).unsqueeze(0).to(dtype)            # [1,T,4,h,w], NOT scaled
     st["cond_latents"] = cond
+    lap("vae_encode_s")
     added = torch.tensor([ADDED_TIME_IDS], dtype=dtype)
     sch = EulerKarrasVPred()
     ts = sch.set_timesteps(steps)
@@ -95,6 +105,7 @@ def run_pipeline(unet, vae, clip, frames_thwc, noise_latents, noise_aug, steps,
             idx_start += stride
         latents = latents_all
     st["latents"] = latents
+    lap("unet_s")
     z = latents.flatten(0, 1) / SCALING
     out = []
     for i in range(0, T, chunk):
@@ -102,6 +113,7 @@ def run_pipeline(unet, vae, clip, frames_thwc, noise_latents, noise_aug, steps,
         out.append(vae.decode(zc, zc.shape[0]))
     fr = torch.cat(out, 0).float()                              # [T,3,H,W]
     fr = (fr / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).contiguous().numpy()
+    lap("vae_decode_s")
     return (fr, st) if return_stages else fr
 
 

@@ -271,6 +271,13 @@ def test_full_architecture_clip_and_vae_encoder_small_clip():
         with torch.no_grad():
             refb = vae.encode_mode(torch.from_numpy(big).permute(0, 3, 1, 2)).numpy()
         assert_close(gotb, refb, 1e-3, "full-size (384x512) full-architecture VAE encode, float32-grade")
+        # the engine's output IS the pipeline's fp16 latent; against the fp32 oracle rounded to fp16 the two agree to the last bit
+        # almost everywhere (a float32-grade interior leaves only round-to-nearest ties on the boundary)
+        refb16 = refb.astype(np.float16).astype(np.float32)
+        ulp = np.abs(gotb.astype(np.float16).view(np.int16).astype(np.int32) - refb16.astype(np.float16).view(np.int16).astype(np.int32))
+        frac = report("full-size VAE encode, float32-grade: fraction of latents != fp16(oracle)", float((ulp != 0).mean()))
+        report("full-size VAE encode, float32-grade: max fp16-ulp distance to fp16(oracle)", float(ulp.max()))
+        assert frac < 0.02 and ulp.max() <= 1, (frac, ulp.max())
     finally:
         pipe.engine.close()
 
