@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path (RCCL process group, all_gather, barriers, "
+                    "max-over-ranks timing) even with one rank - plumbing check for the N > 1 launch on a 1-GPU box")
+    ap.add_argument("--tiny", action="store_true", help="tiny full-topology weights instead of the 1.5 B-parameter architecture (plumbing checks only)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -100,8 +103,10 @@ def main():
 
     import torch
     dist = None
-    if world > 1:
+    multi = world > 1 or a.force_dist
+    if multi:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
 
@@ -111,7 +116,11 @@ def main():
     from unigeo_amd.model.depthcrafter import DepthCrafter
 
     T, H, W = a.frames, a.height, a.width
-    pipe = DepthCrafterPipelineHIP.from_random(seed=42, device_id=local, workspace_bytes=40 << 30)
+    if a.tiny:
+        from unigeo_amd import weights as Wt
+        pipe = DepthCrafterPipelineHIP.from_random(seed=42, cfgs=Wt.tiny_cfgs(), device_id=local, workspace_bytes=3 << 30)
+    else:
+        pipe = DepthCrafterPipelineHIP.from_random(seed=42, device_id=local, workspace_bytes=40 << 30)
     eng = pipe.engine
     clip = synthetic_clip(T, H, W, seed=1234 + rank)
     frames = DepthCrafter.prepare_input(None, clip)
@@ -121,7 +130,7 @@ def main():
 
     def one_clip():
         eng.run(a.denoise_steps, 8, with_normals=False)   # returns after its own stream sync
-        if world > 1:                                      # reassemble outputs: RCCL all_gather over xGMI
+        if multi:                                          # reassemble outputs: RCCL all_gather over xGMI
             ptr, shape = eng.device_ptrs()["depth"]
             local_t = torch.as_tensor(DeviceArray(ptr, shape), device=f"cuda:{local}")
             out = [torch.empty_like(local_t) for _ in range(world)]
@@ -130,17 +139,17 @@ def main():
 
     for _ in range(a.warmup):
         one_clip()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize() if torch.cuda.is_available() else None
     t0 = time.perf_counter()
     for _ in range(a.steps):
         one_clip()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize() if torch.cuda.is_available() else None
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], device=f"cuda:{local}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -215,7 +224,7 @@ def main():
             except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
                 res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}
-    if world > 1:
+    if multi:
         dist.barrier()                  # rank 0 may still be in its (un-timed) profile pass
         dist.destroy_process_group()
     if rank == 0:

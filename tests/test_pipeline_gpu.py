@@ -214,3 +214,38 @@ def test_harness_with_device_metrics(tiny_plugin, tmp_path):
     for a, b in zip(host, dev):
         for k in ("Abs Rel", "delta < 1.25", "normal mean", "normal median"):
             assert b[k] == pytest.approx(a[k], rel=2e-4, abs=1e-3), k
+
+
+def test_multi_gpu_entry_points_run_under_a_single_rank_rccl_group(tmp_path):
+    """BASELINE configs[2] plumbing: the exact code the driver launches on 8 GPUs - bench.py's N > 1 branch (RCCL group, all_gather
+    of engine memory, barriers, max-over-ranks timing) and tools/eval_sharded.py (sharded evaluate -> all_gather_object -> one CSV) -
+    executed end to end as subprocesses with a forced one-rank nccl group, so the first 8-GPU run cannot die on plumbing."""
+    import json, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    env["MASTER_PORT"] = "29561"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--tiny", "--steps", "2", "--warmup", "1",
+                        "--frames", "5", "--height", "64", "--width", "128", "--denoise-steps", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak" and "all_gather" in line["config"]["parallelism"]
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text(textwrap.dedent("""
+        dataset: "SyntheticGeometryDataset"
+        root: "unused"
+        h: 64
+        w: 64
+        clip_length: 9
+        clip_overlap: 1
+        model_name: "DepthCrafter"
+        model_params: {synthetic_weights: true, tiny: true, num_inference_steps: 2, workspace_bytes: 3221225472}
+        eval_depth: {metric_names: ['Abs Rel', 'delta < 1.25'], depth_alignment: "lstsq"}
+        eval_normal: {metric_names: ['normal mean']}
+        """))
+    env["MASTER_PORT"] = "29562"; env["UG_FORCE_DIST"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "eval_sharded.py"), str(cfg)], capture_output=True, text=True,
+                       env=env, cwd=str(tmp_path), timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    csv = (tmp_path / "debug_output" / "metrics.csv").read_text().strip().splitlines()
+    assert csv[-1].startswith("Average") and len(csv) >= 3

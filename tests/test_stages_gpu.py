@@ -271,13 +271,13 @@ def test_full_architecture_clip_and_vae_encoder_small_clip():
         with torch.no_grad():
             refb = vae.encode_mode(torch.from_numpy(big).permute(0, 3, 1, 2)).numpy()
         assert_close(gotb, refb, 1e-3, "full-size (384x512) full-architecture VAE encode, float32-grade")
-        # the engine's output IS the pipeline's fp16 latent; against the fp32 oracle rounded to fp16 the two agree to the last bit
-        # almost everywhere (a float32-grade interior leaves only round-to-nearest ties on the boundary)
-        refb16 = refb.astype(np.float16).astype(np.float32)
-        ulp = np.abs(gotb.astype(np.float16).view(np.int16).astype(np.int32) - refb16.astype(np.float16).view(np.int16).astype(np.int32))
-        frac = report("full-size VAE encode, float32-grade: fraction of latents != fp16(oracle)", float((ulp != 0).mean()))
-        report("full-size VAE encode, float32-grade: max fp16-ulp distance to fp16(oracle)", float(ulp.max()))
-        assert frac < 0.02 and ulp.max() <= 1, (frac, ulp.max())
+        # the engine's output IS the pipeline's fp16 latent: what is left after subtracting the unavoidable half-ulp of that final
+        # fp16 rounding is the error of the float32-grade interior - a few 1e-6 of the output scale, i.e. fp32 round-off
+        half_ulp = np.spacing(np.abs(refb).astype(np.float16)).astype(np.float32) / 2
+        interior = float(np.maximum(np.abs(gotb - refb) - half_ulp, 0).max() / np.abs(refb).max())
+        report("full-size VAE encode, float32-grade: error beyond the final fp16 rounding / max|ref|", interior)
+        report("full-size VAE encode, float32-grade: fraction of latents != fp16(oracle)", float((gotb != refb.astype(np.float16).astype(np.float32)).mean()))
+        assert interior < 2e-5, interior
     finally:
         pipe.engine.close()
 

@@ -11,11 +11,14 @@ from unigeo_amd.harness.distributed import evaluate_sharded
 
 cfg = yaml.safe_load(open(sys.argv[1]))
 world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
-if world > 1:
+multi = world > 1 or os.environ.get("UG_FORCE_DIST") == "1"      # UG_FORCE_DIST=1: take the RCCL path with a single rank (plumbing check)
+if multi:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29542")
+    os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
     torch.cuda.set_device(local)
     dist.init_process_group("nccl")
 ds = import_class_from_module("unigeo_amd.harness", cfg["dataset"])(**parse_dataset_config(cfg))
 model = import_class_from_module("unigeo_amd.model", cfg["model_name"])(device_id=local, **cfg["model_params"])
-rows, mm = evaluate_sharded(cfg, ds, model, dist=dist if world > 1 else None, verbose=(local == 0))
-if world > 1:
+rows, mm = evaluate_sharded(cfg, ds, model, dist=dist if multi else None, verbose=(local == 0))
+if multi:
     dist.destroy_process_group()

@@ -81,12 +81,24 @@ __global__ __launch_bounds__(256) void k_gn32_stats(const Gn32P p, int nchunk, i
   const int rsub = tid / nv, v = tid - rsub * nv;
   const int t = blockIdx.y, r0 = blockIdx.x * rpc, r1 = min(r0 + rpc, p.HW);
   float s = 0.f, q = 0.f;
-  if (rsub < rpi)
-    for (int r = r0 + rsub; r < r1; r += rpi) {
-      const f32x4 x = *(const f32x4*)(p.X + ((long)t * p.HW + r) * p.C + v * 4);
+  if (rsub < rpi) {
+    const float* base = p.X + (long)t * p.HW * p.C + v * 4;
+    int r = r0 + rsub;
+    for (; r + 3 * rpi < r1; r += 4 * rpi) {          // four rows' loads in flight
+      f32x4 x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = *(const f32x4*)(base + (long)(r + u * rpi) * p.C);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s += x[u][e]; q += x[u][e] * x[u][e]; }
+    }
+    for (; r < r1; r += rpi) {
+      const f32x4 x = *(const f32x4*)(base + (long)r * p.C);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { s += x[e]; q += x[e] * x[e]; }
     }
+  }
   rs[tid] = (rsub < rpi) ? (double)s : 0.0; rq[tid] = (rsub < rpi) ? (double)q : 0.0;
   __syncthreads();
   const int cpg = p.C / p.G, vpg = cpg / 4;
@@ -125,9 +137,7 @@ __global__ __launch_bounds__(256) void k_gn32_apply(const Gn32P p, int rpc) {
   float ga[4], be[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) { ga[e] = rstd * (float)p.gamma[c + e]; be[e] = (float)p.beta[c + e]; }
-  for (int r = r0 + rsub; r < r1; r += rpi) {
-    const long m = (long)t * p.HW + r;
-    const f32x4 x = *(const f32x4*)(p.X + m * p.C + c);
+  auto emit = [&](long m, const f32x4 x) {
     f32x4 y;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -139,7 +149,16 @@ __global__ __launch_bounds__(256) void k_gn32_apply(const Gn32P p, int rpc) {
     split4(y, hi, lo);
     *(h4*)(p.Y + m * 2 * p.C + c) = hi;
     *(h4*)(p.Y + m * 2 * p.C + p.C + c) = lo;
+  };
+  int r = r0 + rsub;
+  for (; r + 3 * rpi < r1; r += 4 * rpi) {            // four rows' loads in flight
+    f32x4 x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = *(const f32x4*)(p.X + ((long)t * p.HW + r + u * rpi) * p.C + c);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) emit((long)t * p.HW + r + u * rpi, x[u]);
   }
+  for (; r < r1; r += rpi) emit((long)t * p.HW + r, *(const f32x4*)(p.X + ((long)t * p.HW + r) * p.C + c));
 }
 
 static inline void gn32_chunks(int T, int HW, int C, int& nchunk, int& rpc) {

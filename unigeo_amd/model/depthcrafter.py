@@ -32,8 +32,12 @@ class DepthCrafter:
         if have:
             self.pipeline = DepthCrafterPipelineHIP.from_pretrained(pre_train_path, unet_path, device_id=device_id)
         elif kwargs.get("synthetic_weights", False):
+            cfgs = kwargs.get("cfgs")
+            if cfgs is None and kwargs.get("tiny", False):      # YAML-selectable tiny full-topology configuration (plumbing checks)
+                from .. import weights as W
+                cfgs = W.tiny_cfgs()
             self.pipeline = DepthCrafterPipelineHIP.from_random(seed=int(kwargs.get("weight_seed", 42)),
-                                                                cfgs=kwargs.get("cfgs"), device_id=device_id,
+                                                                cfgs=cfgs, device_id=device_id,
                                                                 workspace_bytes=kwargs.get("workspace_bytes"))
         else:
             raise FileNotFoundError(f"checkpoints not found (unet_path={unet_path!r}, pre_train_path={pre_train_path!r}); "
