@@ -105,6 +105,27 @@ int ug_dc_set_trace(ug_ctx* ctx, float* host_latents, int steps);
  * them to RCCL (torch.distributed) for the cross-GPU gather without a host round trip. */
 int ug_dc_device_ptrs(ug_ctx* ctx, void** frames_dev, void** depth_dev, void** normals_dev);
 
+/* StableNormal: replaces `self.predictor = torch.hub.load("Stable-X/StableNormal", "StableNormal")` (model/stablenormal.py:16) and
+ * `self.predictor(image)` (:39).  The hub predictor's code is un-vendored; what runs here is the restatement documented in
+ * oracle/stablenormal.py / DESIGN.md (UNPINNED): SD AutoencoderKL, two SD-2.1-class UNet2DConditionModels (one-step "YOSO" estimate
+ * + DDIM refinement), two ControlNet trunks (image latent; image latent + DINOv2 tokens) and a DINOv2 ViT-L/14 tower.
+ *   ug_bind_stablenormal : tensors uploaded with ug_load_tensor under "sn.vae.", "sn.unet_yoso.", "sn.controlnet_yoso.", "sn.unet.",
+ *                          "sn.controlnet_dino.", "sn.dino."; sd = UNet2DConditionModel config (ug_unet_config; the SVD-only fields are
+ *                          ignored), dino = ViT config (ug_clip_config; projection_dim ignored)
+ *   ug_sn_run            : images [B,H,W,3] float32 in [0,1] (H, W multiples of 64; the frames of a clip are a batch - the reference
+ *                          loops over them), prompt_embeds [77, cross_attention_dim] float32 (text-encoder output for the fixed
+ *                          prompt, computed once by the caller), YOSO timestep, and the refinement schedule as data: nsteps DDIM
+ *                          timesteps with the per-step update x <- ca[i]*x + cb[i]*unet(x, t_i)  ->  unit normals [B,H,W,3] in [-1,1] */
+int ug_bind_stablenormal(ug_ctx* ctx, const ug_unet_config* sd, const ug_vae_config* vae, const ug_clip_config* dino);
+int ug_sn_run(ug_ctx* ctx, const float* images_bhwc, int B, int H, int W, const float* prompt_embeds, float yoso_timestep, int nsteps,
+              const float* timesteps, const float* ca, const float* cb, float* normals_out);
+/* stage-level (parity tests): which = 0 YOSO pair / 1 refinement pair; use_ctrl: run the matching ControlNet on zimg (and DINO tokens) first */
+int ug_sn_unet_forward(ug_ctx* ctx, int which, const float* sample_bchw, const float* zimg_bchw, int B, int h, int w, float t_unet,
+                       float t_ctrl, const float* prompt_embeds, const float* dino_tokens, int use_ctrl, float* out_bchw);
+int ug_sn_dino(ug_ctx* ctx, const float* images_bhwc, int B, int H, int W, float* tokens_out /*[B, g*g, D]*/);
+int ug_sn_vae_decode(ug_ctx* ctx, const float* z_bchw, int B, int h, int w, float* out_bhwc /*[B,8h,8w,3] raw decoder output*/);
+int ug_sn_vae_encode(ug_ctx* ctx, const float* img_m11_bhwc, int B, int H, int W, float* lat_out /*[B,4,H/8,W/8] posterior mode, unscaled*/);
+
 /* Stage-level entry points (host in / host out) - what the parity tests drive.  Each replaces
  * the corresponding diffusers module call inside the pipeline (un-vendored). */
 int ug_clip_embed(ug_ctx* ctx, const float* frames_thwc, int T, int H, int W, float* emb_out /*[T,proj]*/);

@@ -25,3 +25,13 @@ def oracle_vae(cfg, state):
 
 def oracle_clip(cfg, state):
     return _load(CLIPVisionWithProjection(CLIPConfig(**dataclasses.asdict(cfg))), state)
+
+
+def oracle_stablenormal(cfgs, states):
+    """(SDUNetCfg, VAECfg, DinoCfg) + {component: state} -> the six oracle modules of oracle/stablenormal.py."""
+    from oracle.stablenormal import AutoencoderKL, ControlNet, DinoConfig, DinoV2, SDUNet, SDUNetConfig
+    u, v, d = cfgs
+    uc = SDUNetConfig(**dataclasses.asdict(u)); vc = VAEConfig(**dataclasses.asdict(v)); dc = DinoConfig(**dataclasses.asdict(d))
+    return dict(vae=_load(AutoencoderKL(vc), states["vae"]), unet_y=_load(SDUNet(uc), states["unet_yoso"]),
+                ctrl_y=_load(ControlNet(uc), states["controlnet_yoso"]), unet_r=_load(SDUNet(uc), states["unet"]),
+                ctrl_d=_load(ControlNet(uc, dino_dim=d.hidden_size), states["controlnet_dino"]), dino=_load(DinoV2(dc), states["dino"]))

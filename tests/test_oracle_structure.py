@@ -78,3 +78,38 @@ def test_weight_loader_rejects_wrong_architecture():
     bad = dict(st); bad["conv_in.weight"] = np.zeros((1, 2, 3, 3), np.float16)
     with pytest.raises(ValueError):
         W.check_against_manifest(bad, W.unet_manifest(u), "unet")
+
+
+def test_stablenormal_restatement_structure():
+    """Known answers for the StableNormal restatement (un-vendored hub repo, PARITY UNPINNED): the published parameter counts of the
+    SD 2.1 UNet2DConditionModel (865 910 724) and the SD AutoencoderKL (83 653 863), the ControlNet trunk, DINOv2 ViT-L/14 at a
+    16x16 grid; the engine's manifests (what real safetensors are checked against) list exactly the oracle's state-dict keys/shapes."""
+    import dataclasses
+    from oracle.stablenormal import AutoencoderKL, ControlNet, DinoV2, SDUNet
+    from unigeo_amd import weights as W
+    mods = {"unet": (SDUNet(), W.sd_unet_manifest(), 865_910_724), "controlnet": (ControlNet(), W.controlnet_manifest(), 363_141_760),
+            "controlnet_dino": (ControlNet(dino_dim=1024), W.controlnet_manifest(dino_dim=1024), 363_141_760 + 1024 * 320 + 320),
+            "vae": (AutoencoderKL(), W.sd_vae_manifest(), 83_653_863), "dino": (DinoV2(), W.dino_manifest(), 303_227_904)}
+    for name, (m, man, count) in mods.items():
+        sd = m.state_dict()
+        assert sum(v.numel() for v in sd.values()) == count, name
+        assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v) for k, v in man.items()}, name
+
+
+def test_stablenormal_ddim_tables_and_plugin_refusal():
+    import numpy as np
+    import pytest
+    from unigeo_amd.stablenormal import ddim_tables, normals_to_uint8, refine_timesteps
+    from oracle.stablenormal import ddim_tables as o_tables
+    ts = refine_timesteps(401, 10)
+    assert ts[0] == 401 and len(ts) == 10 and all(a > b for a, b in zip(ts, ts[1:]))
+    for pt in ("epsilon", "v_prediction", "sample"):
+        a, b = ddim_tables(ts, pt); a2, b2 = o_tables(ts, pt)
+        assert np.array_equal(a, a2) and np.array_equal(b, b2)
+    # closed form: the last step lands on alpha_bar_prev = 1, i.e. x <- x0;  for sample prediction that is a = 0, b = 1
+    a, b = ddim_tables(ts, "sample")
+    assert abs(a[-1]) < 1e-7 and abs(b[-1] - 1) < 1e-7
+    assert normals_to_uint8(np.array([[-1.0, 0.0, 1.0]]))[0].tolist() == [0, 127, 255]
+    from unigeo_amd.model import StableNormal
+    with pytest.raises(FileNotFoundError):
+        StableNormal(model_dir="/nonexistent/dir")

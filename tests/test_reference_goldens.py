@@ -82,5 +82,5 @@ def test_g7_stablenormal_uint8_wrap():
     plug = StableNormal(predictor=lambda im: np.array(im))
     res = plug.forward({"images": [np.transpose(i, (2, 0, 1)).astype(np.float32) for i in imgs]})
     np.testing.assert_array_equal(res["pred_normals"].numpy(), G["g7_normals"])
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(FileNotFoundError):       # no checkpoints, no synthetic_weights=True, no predictor: refused, never faked
         StableNormal()

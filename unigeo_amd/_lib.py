@@ -22,6 +22,7 @@ EXPORTS = [
     "ug_eval_depth", "ug_eval_normal", "ug_clip_embed", "ug_vae_encode", "ug_vae_decode", "ug_unet_forward", "ug_normals_from_depth",
     "ug_op_linear", "ug_op_conv", "ug_op_groupnorm", "ug_op_layernorm", "ug_op_flash_attn",
     "ug_op_temporal_attn", "ug_op_attention_generic", "ug_op_euler_step",
+    "ug_bind_stablenormal", "ug_sn_run", "ug_sn_unet_forward", "ug_sn_dino", "ug_sn_vae_decode", "ug_sn_vae_encode",
     "ug_profile_begin", "ug_profile_begin_shapes", "ug_profile_end", "ug_bench_gemm", "ug_bench_groupnorm", "ug_tune_force",
 ]
 
@@ -96,6 +97,12 @@ def load_library():
     lib.ug_op_temporal_attn.argtypes = [vp, vp, ip, ip, ip, vp]
     lib.ug_op_attention_generic.argtypes = [vp, vp, ip, ip, ip, ip, vp]
     lib.ug_op_euler_step.argtypes = [vp, vp, vp, C.c_long, C.c_float, C.c_float]
+    lib.ug_bind_stablenormal.argtypes = [vp, C.POINTER(UNetConfigC), C.POINTER(VAEConfigC), C.POINTER(CLIPConfigC)]
+    lib.ug_sn_run.argtypes = [vp, vp, ip, ip, ip, vp, C.c_float, ip, vp, vp, vp, vp]
+    lib.ug_sn_unet_forward.argtypes = [vp, ip, vp, vp, ip, ip, ip, C.c_float, C.c_float, vp, vp, ip, vp]
+    lib.ug_sn_dino.argtypes = [vp, vp, ip, ip, ip, vp]
+    lib.ug_sn_vae_decode.argtypes = [vp, vp, ip, ip, ip, vp]
+    lib.ug_sn_vae_encode.argtypes = [vp, vp, ip, ip, ip, vp]
     lib.ug_profile_begin.argtypes = [vp]
     lib.ug_bench_gemm.argtypes = [vp] + [ip] * 16 + [vp]
     lib.ug_bench_groupnorm.argtypes = [vp, ip, ip, ip, ip, ip, ip, ip, vp]
@@ -192,6 +199,61 @@ class Engine:
         c.layer_norm_eps = cfg.layer_norm_eps
         self._ck(self.lib.ug_bind_clip(self.ctx, C.byref(c)))
         self.clip_cfg = cfg
+
+    # ---- StableNormal
+    def bind_stablenormal(self, ucfg, vcfg, dcfg):
+        u = UNetConfigC()
+        u.in_channels, u.out_channels, u.num_levels = ucfg.in_channels, ucfg.out_channels, len(ucfg.block_out_channels)
+        _fill8(u.block_out_channels, ucfg.block_out_channels); _fill8(u.num_attention_heads, ucfg.num_attention_heads)
+        _fill8(u.down_has_attn, [int(b) for b in ucfg.down_has_attn])
+        u.layers_per_block, u.cross_attention_dim, u.norm_groups = ucfg.layers_per_block, ucfg.cross_attention_dim, ucfg.norm_groups
+        v = VAEConfigC()
+        v.in_channels, v.out_channels, v.latent_channels = vcfg.in_channels, vcfg.out_channels, vcfg.latent_channels
+        v.num_levels = len(vcfg.block_out_channels)
+        _fill8(v.block_out_channels, vcfg.block_out_channels)
+        v.layers_per_block, v.norm_groups, v.scaling_factor = vcfg.layers_per_block, vcfg.norm_groups, vcfg.scaling_factor
+        d = CLIPConfigC()
+        d.hidden_size, d.intermediate_size, d.num_hidden_layers = dcfg.hidden_size, dcfg.intermediate_size, dcfg.num_hidden_layers
+        d.num_attention_heads, d.image_size, d.patch_size, d.layer_norm_eps = dcfg.num_attention_heads, dcfg.image_size, dcfg.patch_size, dcfg.layer_norm_eps
+        self._ck(self.lib.ug_bind_stablenormal(self.ctx, C.byref(u), C.byref(v), C.byref(d)))
+        self.sn_cfgs = (ucfg, vcfg, dcfg)
+
+    def sn_run(self, images, prompt_embeds, yoso_t, timesteps, ca, cb):
+        f = _f32(images); B, H, W, _ = f.shape
+        pe = _f32(prompt_embeds).reshape(77, self.sn_cfgs[0].cross_attention_dim)
+        ts, a, b = _f32(timesteps), _f32(ca), _f32(cb)
+        out = np.empty((B, H, W, 3), np.float32)
+        self._ck(self.lib.ug_sn_run(self.ctx, _ptr(f), B, H, W, _ptr(pe), float(yoso_t), int(ts.size), _ptr(ts), _ptr(a), _ptr(b), _ptr(out)))
+        return out
+
+    def sn_unet_forward(self, which, sample, t_unet, prompt_embeds, zimg=None, t_ctrl=0.0, dino_tokens=None, use_ctrl=False):
+        s = _f32(sample); B, _, h, w = s.shape
+        z = None if zimg is None else _f32(zimg)
+        d = None if dino_tokens is None else _f32(dino_tokens)
+        pe = _f32(prompt_embeds)
+        out = np.empty((B, 4, h, w), np.float32)
+        self._ck(self.lib.ug_sn_unet_forward(self.ctx, int(which), _ptr(s), _ptr(z), B, h, w, float(t_unet), float(t_ctrl), _ptr(pe), _ptr(d),
+                                             int(bool(use_ctrl)), _ptr(out)))
+        return out
+
+    def sn_dino(self, images):
+        f = _f32(images); B, H, W, _ = f.shape
+        dc = self.sn_cfgs[2]; g = dc.image_size // dc.patch_size
+        out = np.empty((B, g * g, dc.hidden_size), np.float32)
+        self._ck(self.lib.ug_sn_dino(self.ctx, _ptr(f), B, H, W, _ptr(out)))
+        return out
+
+    def sn_vae_decode(self, z):
+        z = _f32(z); B, _, h, w = z.shape
+        out = np.empty((B, 8 * h, 8 * w, 3), np.float32)
+        self._ck(self.lib.ug_sn_vae_decode(self.ctx, _ptr(z), B, h, w, _ptr(out)))
+        return out
+
+    def sn_vae_encode(self, img_m11):
+        f = _f32(img_m11); B, H, W, _ = f.shape
+        out = np.empty((B, 4, H // 8, W // 8), np.float32)
+        self._ck(self.lib.ug_sn_vae_encode(self.ctx, _ptr(f), B, H, W, _ptr(out)))
+        return out
 
     # ---- pipeline
     def set_inputs(self, frames, noise_latents, noise_aug, intrinsics=None):

@@ -251,6 +251,84 @@ int ug_unet_forward(ug_ctx* x, const float* sample, int T, int h, int w, float t
   });
 }
 
+// ---------------------------------------------------------------- StableNormal (reference model/stablenormal.py:16,39)
+static UNetCfg sd_cfg_from(const ug_unet_config* g) {
+  UNetCfg u; u.in_ch = g->in_channels; u.out_ch = g->out_channels; u.nlev = g->num_levels;
+  for (int i = 0; i < 8; ++i) { u.boc[i] = g->block_out_channels[i]; u.heads[i] = g->num_attention_heads[i]; u.has_attn[i] = g->down_has_attn[i]; }
+  u.layers = g->layers_per_block; u.cross_dim = g->cross_attention_dim; u.groups = g->norm_groups;
+  return u;
+}
+int ug_bind_stablenormal(ug_ctx* x, const ug_unet_config* gu, const ug_vae_config* gv, const ug_clip_config* gd) {
+  UG_TRY(x, {
+    UG_REQUIRE(gu && gv && gd, "null config");
+    UG_REQUIRE(gu->num_levels >= 2 && gu->num_levels <= 8 && gv->num_levels >= 2 && gv->num_levels <= 8, "num_levels out of range");
+    VAECfg v; v.in_ch = gv->in_channels; v.out_ch = gv->out_channels; v.lat = gv->latent_channels; v.nlev = gv->num_levels;
+    for (int i = 0; i < 8; ++i) v.boc[i] = gv->block_out_channels[i];
+    v.layers = gv->layers_per_block; v.groups = gv->norm_groups; v.scaling = gv->scaling_factor;
+    CLIPCfg d; d.hidden = gd->hidden_size; d.inter = gd->intermediate_size; d.layers = gd->num_hidden_layers; d.heads = gd->num_attention_heads;
+    d.image = gd->image_size; d.patch = gd->patch_size; d.proj = 0; d.eps = gd->layer_norm_eps;
+    bind_sn(x->c, sd_cfg_from(gu), v, d, "sn.");
+    finish_binding(x->c, "sn.");
+  });
+}
+int ug_sn_run(ug_ctx* x, const float* images, int B, int H, int W, const float* prompt, float yoso_t, int nsteps, const float* timesteps,
+              const float* ca, const float* cb, float* normals_out) {
+  UG_TRY(x, sn_run(x->c, images, B, H, W, prompt, yoso_t, nsteps, timesteps, ca, cb, normals_out));
+}
+int ug_sn_unet_forward(ug_ctx* x, int which, const float* sample, const float* zimg, int B, int h, int w, float t_unet, float t_ctrl,
+                       const float* prompt, const float* dino_tokens, int use_ctrl, float* out) {
+  UG_TRY(x, {
+    Ctx& c = x->c; Scope sc(c);
+    SN& s = c.sn;
+    UG_REQUIRE(s.bound, "StableNormal weights are not bound");
+    f16* ds = up_nchw(c, sample, B, 4, h, w, 4);
+    f16* dz = zimg ? up_nchw(c, zimg, B, 4, h, w, 4) : nullptr;
+    f16* dp = up16(c, prompt, 77L * s.cfg.cross_dim);
+    const int g = s.dino.cfg.image / s.dino.cfg.patch;
+    f16* dt = dino_tokens ? up16(c, dino_tokens, (long)B * g * g * s.dino.cfg.hidden) : nullptr;
+    UG_REQUIRE(!use_ctrl || dz, "ControlNet evaluation needs the image latent");
+    f16* y = sn_unet_eval(c, which, ds, dz, B, h, w, t_unet, t_ctrl, dp, dt, use_ctrl);
+    down_nchw(c, y, out, B, 4, h, w);
+  });
+}
+int ug_sn_dino(ug_ctx* x, const float* images01, int B, int H, int W, float* tokens_out) {
+  UG_TRY(x, {
+    Ctx& c = x->c; Scope sc(c);
+    const long px = (long)B * H * W;
+    float* df = c.ws.get<float>(px * 3);
+    UG_CHECK(hipMemcpy(df, images01, px * 3 * 4, hipMemcpyHostToDevice));
+    f16* src = c.ws.get<f16>(px * 3); f16* vin = c.ws.get<f16>(px * 8);
+    launch_prep_video(df, df, src, vin, B, H, W, 0.f, c.stream);
+    f16* t = sn_dino_tokens(c, src, B, H, W);
+    const int g = c.sn.dino.cfg.image / c.sn.dino.cfg.patch;
+    down16(c, t, tokens_out, (long)B * g * g * c.sn.dino.cfg.hidden);
+  });
+}
+int ug_sn_vae_decode(ug_ctx* x, const float* z, int B, int h, int w, float* out_bhwc) {
+  UG_TRY(x, {
+    Ctx& c = x->c; Scope sc(c);
+    f16* dz = up_nchw(c, z, B, 4, h, w, 4);
+    f16* rgb = sn_vae_decode(c, dz, B, h, w);
+    const long px = (long)B * h * 8 * w * 8;
+    std::vector<f16> v((size_t)px * 8);
+    UG_CHECK(hipStreamSynchronize(c.stream));
+    UG_CHECK(hipMemcpy(v.data(), rgb, v.size() * 2, hipMemcpyDeviceToHost));
+    for (long p = 0; p < px; ++p) for (int ch = 0; ch < 3; ++ch) out_bhwc[p * 3 + ch] = (float)v[p * 8 + ch];
+  });
+}
+int ug_sn_vae_encode(ug_ctx* x, const float* video, int B, int H, int W, float* lat_out) {
+  UG_TRY(x, {
+    Ctx& c = x->c; Scope sc(c);
+    const long px = (long)B * H * W;
+    std::vector<f16> v((size_t)px * 8, (f16)0.f);
+    for (long p = 0; p < px; ++p) for (int ch = 0; ch < 3; ++ch) v[p * 8 + ch] = (f16)video[p * 3 + ch];
+    f16* d = c.ws.get<f16>(px * 8);
+    UG_CHECK(hipMemcpy(d, v.data(), v.size() * 2, hipMemcpyHostToDevice));
+    f16* l = vae_encode_v(c, c.sn.vae, d, B, H, W, false);
+    down_nchw(c, l, lat_out, B, c.sn.vae.cfg.lat, H / 8, W / 8);
+  });
+}
+
 int ug_normals_from_depth(ug_ctx* x, const float* depth, const float* K, int T, int H, int W, float* normals) {
   UG_TRY(x, {
     Ctx& c = x->c; Scope sc(c);

@@ -101,10 +101,13 @@ void launch_layernorm(const LayerNormP& p, hipStream_t s);
 // ---------------------------------------------------------------------------------------
 // Flash-style self-attention, head_dim 64.  Q/K/V are column slices of row-major matrices
 // (row stride ld*), batch b = frame, rows [b*S, (b+1)*S), head h at columns [h*64, h*64+64).
+// Cross-attention: Sk != 0 gives the key/value sequence length (queries keep S); kv_shared = 1 makes every batch read the
+// same Sk key/value rows (a text context computed once), otherwise batch b's keys are rows [b*Sk, (b+1)*Sk).
 struct FlashP {
   const f16* Q; const f16* K; const f16* V; long ldq, ldk, ldv;
   f16* O; long ldo;
   int B, H, S; float scale;
+  int Sk = 0; int kv_shared = 0;
 };
 void launch_flash_attn64(const FlashP& p, hipStream_t s);
 
@@ -146,7 +149,10 @@ void launch_axpby(const f16* a, const f16* b, f16* y, float ca, float cb, long n
 void launch_prep_video(const float* frames, const float* noise, f16* clip_src, f16* vae_in,
                        int T, int H, int W, float noise_aug, hipStream_t s);
 void launch_clip_patchify(const f16* video_m11, f16* patches, int T, int H, int W, int S224,
-                          int P, int Kpad, hipStream_t s);
+                          int P, int Kpad, hipStream_t s, int imagenet_norm = 0);   // 0: CLIP mean/std, 1: ImageNet mean/std (DINOv2)
+void launch_scale_rows(f16* w, const f16* gamma, int N, int K, hipStream_t s);     // w[n][:] *= gamma[n] (LayerScale folded into a projection)
+void launch_add_grid_nearest(f16* x, const f16* grid, int B, int h, int w, int g, int C, hipStream_t s);   // x[b,y,x,:] += grid[b, y*g/h, x*g/w, :]
+void launch_sn_normals_out(const f16* dec, int ldd, float* out, long pixels, hipStream_t s);   // clip to [-1,1], L2-normalise -> f32 [pixels,3]
 void launch_init_latents2(const float* noise, f16* lat, float sigma0, int T, long hw, hipStream_t s);
 void launch_silu_f16(const f16* in, f16* out, long n, hipStream_t s);
 void launch_clip_assemble(const f16* patches, const f16* cls, const f16* pos, f16* tok, int T, int np, int d,

@@ -84,14 +84,40 @@ struct VAE {
   std::vector<STRes> dmid; VAttn dattn;
   struct DUp { std::vector<STRes> res; Conv up; bool has_up = false; };
   std::vector<DUp> dup;
+  // plain 2-D decoder of the SD AutoencoderKL (StableNormal): mid res blocks, per-level res blocks (upsamplers live in dup[i].up)
+  bool dec2d = false; Conv post_quant; std::vector<Res2D> d2_mid; std::vector<std::vector<Res2D>> d2_up;
 };
 
 struct CLIPLayer { Norm ln1, ln2; Lin qkv, out, fc1, fc2; };
 struct CLIP {
   CLIPCfg cfg; bool bound = false;
   const f16* patch_w = nullptr; int patch_k = 0;  // [hidden][Kpad]
+  const f16* patch_b = nullptr;                   // DINOv2's patch embedding has a bias (CLIP's has none)
   const f16* cls = nullptr; const f16* pos = nullptr;
   Norm pre, post; std::vector<CLIPLayer> layers; Lin proj;
+};
+
+// ---- StableNormal (BASELINE configs[3]): SD-2.1-class UNet2DConditionModel / ControlNet trunk, DINOv2 tower (sn_graphs.inc) ----
+struct SDTransformer {
+  int C = 0, heads = 0;
+  Norm gn; Lin proj_in, proj_out; Norm ln1, ln2, ln3; Lin qkv1, o1, q2, kv2, o2, ff1, ff2;
+  f16* kv = nullptr;    // per-run cache: [77][2C] = to_k | to_v of the text context
+};
+struct TembSet { std::vector<Res2D*> res; f16* tproj = nullptr; std::vector<long> off; int steps = 0; };
+struct SDTrunk {
+  Conv conv_in; Lin te1, te2;
+  struct Down { std::vector<Res2D> res; std::vector<SDTransformer> attn; Conv down; bool has_down = false; };
+  std::vector<Down> down; Res2D mid0, mid1; SDTransformer mid_attn;
+};
+struct SDUNetM {
+  SDTrunk tr; TembSet ts;
+  struct Up { std::vector<Res2D> res; std::vector<SDTransformer> attn; Conv up; bool has_up = false; };
+  std::vector<Up> up; Norm norm_out; Conv conv_out;
+};
+struct ControlNetM { SDTrunk tr; TembSet ts; std::vector<Conv> zero; Conv zero_mid; Lin dino_proj; bool has_dino = false; };
+struct SN {
+  UNetCfg cfg; bool bound = false;
+  SDUNetM unet_y, unet_r; ControlNetM ctrl_y, ctrl_d; VAE vae; CLIP dino;
 };
 
 struct ProfRec { std::string name; double flops, bytes; hipEvent_t e0, e1; };
@@ -103,7 +129,7 @@ struct Ctx {
   f16* zero = nullptr;
   std::string err;
   std::unordered_map<std::string, RawTensor> raw;
-  UNet unet; VAE vae; CLIP clip;
+  UNet unet; VAE vae; CLIP clip; SN sn;
   // profiling
   bool prof_on = false; bool prof_shapes = false; std::vector<ProfRec> prof; std::string prof_json;
   // resident pipeline I/O
@@ -131,6 +157,19 @@ f16* unet_forward(Ctx& c, const f16* x, int T, int h, int w, int step);   // -> 
 f16* vae_encode(Ctx& c, const f16* x8, int T, int H, int W);              // x8 [T,H,W,8] -> [T,H/8,W/8,4]; precision per c.vae_encode_fp32
 void vae_decode(Ctx& c, const f16* z, int T, int h, int w, float* frames_out);  // z [T,h,w,4] (already /scaling) -> f32 [T,8h,8w,3]
 f16* clip_embed(Ctx& c, const f16* video_m11, int T, int H, int W);       // [T,H,W,3] -> [T,proj]
+
+f16* vae_encode_v(Ctx& c, VAE& v, const f16* x8, int T, int H, int W, bool fp32_grade);
+
+// ---- StableNormal (sn_graphs.inc) ----
+void bind_sn(Ctx& c, const UNetCfg& ucfg, const VAECfg& vcfg, const CLIPCfg& dcfg, const std::string& prefix);   // "<prefix>{vae,unet_yoso,controlnet_yoso,unet,controlnet_dino,dino}."
+// images f32 [B,H,W,3] in [0,1] (host), prompt f32 [77,cross] (host) -> normals f32 [B,H,W,3] (host)
+void sn_run(Ctx& c, const float* images, int B, int H, int W, const float* prompt, float yoso_t, int nsteps, const float* timesteps,
+            const float* ca, const float* cb, float* normals_out);
+// stage-level (parity tests): which = 0 YOSO pair, 1 refinement pair; device tensors, channels-last fp16
+f16* sn_unet_eval(Ctx& c, int which, const f16* sample4, const f16* zimg4, int B, int h, int w, float t_unet, float t_ctrl, const f16* prompt,
+                  const f16* dino_tok, int use_ctrl);
+f16* sn_dino_tokens(Ctx& c, const f16* img_m11, int B, int H, int W);          // [B, g*g, D]
+f16* sn_vae_decode(Ctx& c, const f16* z4, int B, int h, int w);                // [B, 8h, 8w, 8] (3 valid channels), raw decoder output
 
 // ---- pipeline ----
 void dc_set_inputs(Ctx& c, const float* frames, int T, int H, int W, const float* noise_lat, const float* noise_aug,

@@ -468,8 +468,10 @@ static VAttn bind_vattn(Ctx& c, const std::string& p, int C) {
   return a;
 }
 
-void bind_vae(Ctx& c, const VAECfg& cfg, const std::string& pre) {
-  VAE& v = c.vae; v = VAE(); v.cfg = cfg;
+static Res2D bind_res2d(Ctx& c, const std::string& p, int cin, int cout, int temb, float eps);
+// temporal_decoder: AutoencoderKLTemporalDecoder (SVD / DepthCrafter); otherwise the plain SD AutoencoderKL decoder + post_quant_conv
+void bind_vae_into(Ctx& c, VAE& v, const VAECfg& cfg, const std::string& pre, bool temporal_decoder) {
+  v = VAE(); v.cfg = cfg;
   const int n = cfg.nlev;
   v.e_in = bind_conv(c, pre + "encoder.conv_in", cfg.in_ch, cfg.boc[0], 1, 3);
   v.edown.resize(n);
@@ -491,9 +493,30 @@ void bind_vae(Ctx& c, const VAECfg& cfg, const std::string& pre) {
   v.e_out = bind_conv(c, pre + "encoder.conv_out", ch, 2 * cfg.lat, 1, 3);
   v.quant = bind_conv(c, pre + "quant_conv", 2 * cfg.lat, 2 * cfg.lat, 1, 1);
   v.d_in = bind_conv(c, pre + "decoder.conv_in", cfg.lat, cfg.boc[n - 1], 1, 3);
+  v.dattn = bind_vattn(c, pre + "decoder.mid_block.attentions.0", cfg.boc[n - 1]);
+  v.d_norm = bind_norm(c, pre + "decoder.conv_norm_out", cfg.boc[0], 1e-6f);
+  v.d_out = bind_conv(c, pre + "decoder.conv_out", cfg.boc[0], cfg.out_ch, 1, 3);
+  if (!temporal_decoder) {
+    v.post_quant = bind_conv(c, pre + "post_quant_conv", cfg.lat, cfg.lat, 1, 1);
+    v.d2_mid.push_back(bind_res2d(c, pre + "decoder.mid_block.resnets.0", cfg.boc[n - 1], cfg.boc[n - 1], 0, 1e-6f));
+    v.d2_mid.push_back(bind_res2d(c, pre + "decoder.mid_block.resnets.1", cfg.boc[n - 1], cfg.boc[n - 1], 0, 1e-6f));
+    v.dup.resize(n); v.d2_up.resize(n);
+    int out2 = cfg.boc[n - 1];
+    for (int i = 0; i < n; ++i) {
+      const int prev = out2; out2 = cfg.boc[n - 1 - i];
+      for (int j = 0; j < cfg.layers + 1; ++j)
+        v.d2_up[i].push_back(bind_res2d(c, pre + "decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j),
+                                        j == 0 ? prev : out2, out2, 0, 1e-6f));
+      if (i != n - 1) {
+        v.dup[i].up = bind_conv(c, pre + "decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", out2, out2, 1, 3, true, true);
+        v.dup[i].has_up = true;
+      }
+    }
+    v.dec2d = true;
+  }
+  if (temporal_decoder) {
   for (int j = 0; j < cfg.layers; ++j)
     v.dmid.push_back(bind_stres(c, pre + "decoder.mid_block.resnets." + std::to_string(j), cfg.boc[n - 1], cfg.boc[n - 1], 0, 1e-6f, 1e-5f, true));
-  v.dattn = bind_vattn(c, pre + "decoder.mid_block.attentions.0", cfg.boc[n - 1]);
   v.dup.resize(n);
   int out = cfg.boc[n - 1];
   for (int i = 0; i < n; ++i) {
@@ -506,11 +529,10 @@ void bind_vae(Ctx& c, const VAECfg& cfg, const std::string& pre) {
       v.dup[i].has_up = true;
     }
   }
-  v.d_norm = bind_norm(c, pre + "decoder.conv_norm_out", cfg.boc[0], 1e-6f);
-  v.d_out = bind_conv(c, pre + "decoder.conv_out", cfg.boc[0], cfg.out_ch, 1, 3);
   UG_REQUIRE(cfg.out_ch == 3, "time_conv_out kernel is written for 3 output channels");
   v.tco_w = persist_f16(c, raw_get(c, pre + "decoder.time_conv_out.weight", {3, 3, 3, 1, 1}));
   v.tco_b = persist_f16(c, raw_get(c, pre + "decoder.time_conv_out.bias", {3}));
+  }
   // float32-grade encoder (reference: force_upcast): K-doubled weights, +2x the encoder's 34 M parameters
   v.edown_w.resize(n);
   for (int i = 0; i < n; ++i) {
@@ -525,6 +547,7 @@ void bind_vae(Ctx& c, const VAECfg& cfg, const std::string& pre) {
   v.wide_bound = true;
   v.bound = true;
 }
+void bind_vae(Ctx& c, const VAECfg& cfg, const std::string& pre) { bind_vae_into(c, c.vae, cfg, pre, true); }
 
 void bind_clip(Ctx& c, const CLIPCfg& cfg, const std::string& pre) {
   CLIP& m = c.clip; m = CLIP(); m.cfg = cfg;
@@ -954,8 +977,7 @@ static void vattn_wide(Ctx& c, const VAttn& at, const float* x, int T, int hw, i
   c.ws.release(mk);
 }
 
-static f16* vae_encode_wide(Ctx& c, const f16* x8, int T, int H, int W) {
-  VAE& v = c.vae;
+static f16* vae_encode_wide(Ctx& c, VAE& v, const f16* x8, int T, int H, int W) {
   UG_REQUIRE(v.wide_bound, "float32-grade VAE encoder weights are not bound");
   const VAECfg& cfg = v.cfg; const int G = cfg.groups, n = cfg.nlev;
   int hh = H, ww = W;
@@ -1002,9 +1024,9 @@ static f16* vae_encode_wide(Ctx& c, const f16* x8, int T, int H, int W) {
   return lat;
 }
 
-f16* vae_encode(Ctx& c, const f16* x8, int T, int H, int W) {
-  if (c.vae_encode_fp32) return vae_encode_wide(c, x8, T, H, W);
-  VAE& v = c.vae;
+f16* vae_encode(Ctx& c, const f16* x8, int T, int H, int W) { return vae_encode_v(c, c.vae, x8, T, H, W, c.vae_encode_fp32 != 0); }
+f16* vae_encode_v(Ctx& c, VAE& v, const f16* x8, int T, int H, int W, bool fp32_grade) {
+  if (fp32_grade) return vae_encode_wide(c, v, x8, T, H, W);
   UG_REQUIRE(v.bound, "VAE weights are not bound");
   const VAECfg& cfg = v.cfg; const int G = cfg.groups;
   UG_REQUIRE(v.e_in.cinp == 8, "encoder input is staged as 8 channels");
@@ -1047,7 +1069,7 @@ f16* vae_encode(Ctx& c, const f16* x8, int T, int H, int W) {
 
 void vae_decode(Ctx& c, const f16* z, int T, int h, int w, float* frames_out) {
   VAE& v = c.vae;
-  UG_REQUIRE(v.bound, "VAE weights are not bound");
+  UG_REQUIRE(v.bound && !v.dec2d, "temporal VAE decoder weights are not bound");
   const VAECfg& cfg = v.cfg; const int G = cfg.groups, n = cfg.nlev;
   UG_REQUIRE(v.d_in.cinp == 8, "decoder input is staged as 8 channels");
   const size_t mk = c.ws.mark();
@@ -1280,5 +1302,7 @@ void dc_get_outputs(Ctx& c, float* frames, float* depth, float* normals) {
   if (depth) UG_CHECK(hipMemcpy(depth, c.d_depth, px * 4, hipMemcpyDeviceToHost));
   if (normals) UG_CHECK(hipMemcpy(normals, c.d_normals, px * 3 * 4, hipMemcpyDeviceToHost));
 }
+
+#include "sn_graphs.inc"
 
 }  // namespace ug

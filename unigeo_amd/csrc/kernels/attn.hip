@@ -139,6 +139,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const FlashP p) {
   const int b = blockIdx.z, h = blockIdx.y;
   const int q0 = blockIdx.x * (128 * FA_QB) + wave * (32 * FA_QB);
   const long row0 = (long)b * p.S;
+  const int Sk = p.Sk ? p.Sk : p.S;                       // cross-attention: keys / values have their own length ...
+  const long rowk = p.kv_shared ? 0 : (long)b * Sk;       // ... and may be one context shared by every batch
   const int qi = lane & 31, hh = lane >> 5;
   const float sc = p.scale * 1.4426950408889634f;
 
@@ -166,9 +168,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const FlashP p) {
       const int key = kv0 + r;
       // out-of-range keys: re-read key 0 (always valid); their scores are masked and their P is exactly 0,
       // so the (finite) V rows they bring in contribute nothing.
-      const long krow = key < p.S ? key : 0;
-      const f16* ks = p.K + (row0 + krow) * p.ldk + h * 64 + ((pc ^ kswz(r)) * 8);
-      const f16* vs = p.V + (row0 + krow) * p.ldv + h * 64 + ((pc ^ vswz(r)) * 8);
+      const long krow = key < Sk ? key : 0;
+      const f16* ks = p.K + (rowk + krow) * p.ldk + h * 64 + ((pc ^ kswz(r)) * 8);
+      const f16* vs = p.V + (rowk + krow) * p.ldv + h * 64 + ((pc ^ vswz(r)) * 8);
       __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(kd + (wave * 16 + j * 8) * 64), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)vs, (lptr_t)(vd + (wave * 16 + j * 8) * 64), 16, 0, 0);
     }
@@ -185,8 +187,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const FlashP p) {
       for (int r = 0; r < 16; ++r) o[qb][dt][r] = 0.f;
   }
 
-  const int ntile = (p.S + FA_KV - 1) / FA_KV;
-  const int nfull = p.S / FA_KV;
+  const int ntile = (Sk + FA_KV - 1) / FA_KV;
+  const int nfull = Sk / FA_KV;
 #pragma unroll
   for (int s0 = 0; s0 < FA_NST - 1; ++s0)
     if (s0 < ntile) stage(s0 * FA_KV, s0);
@@ -203,8 +205,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const FlashP p) {
     if (++ld == FA_NST) ld = 0;
     const f16* kt = lds + buf * (2 * FA_KV * 64);
     const f16* vt = kt + FA_KV * 64;
-    if (t < nfull) fa_tile<false>(kt, vt, qf, lane, t * FA_KV, p.S, sc, m_run, l_run, o);
-    else fa_tile<true>(kt, vt, qf, lane, t * FA_KV, p.S, sc, m_run, l_run, o);
+    if (t < nfull) fa_tile<false>(kt, vt, qf, lane, t * FA_KV, Sk, sc, m_run, l_run, o);
+    else fa_tile<true>(kt, vt, qf, lane, t * FA_KV, Sk, sc, m_run, l_run, o);
     if (++buf == FA_NST) buf = 0;
   }
 #pragma unroll

@@ -164,12 +164,12 @@ __device__ __forceinline__ void cubic_w(float t, float (&w)[4]) {
   x = 1.f - t;       w[2] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
   x = 2.f - t;       w[3] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
 }
+struct Norm3 { float mean[3], stdv[3]; };
 __global__ void k_clip_patchify(const f16* src, f16* patches, int T, int H, int W, int S224, int P, int Kpad,
-                                BlurTaps bt) {
+                                BlurTaps bt, Norm3 nm) {
   const long n = (long)T * S224 * S224;
   const int np = S224 / P;
-  const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
-  const float stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};
+  const float* mean = nm.mean; const float* stdv = nm.stdv;
   GS_LOOP(idx, n) {
     const int ox = idx % S224, oy = (idx / S224) % S224;
     const long t = idx / ((long)S224 * S224);
@@ -219,12 +219,51 @@ static void gauss_taps(int src, int dst, int& ks, float* g) {
   for (int i = 0; i < ks; ++i) g[i] /= sum;
 }
 void launch_clip_patchify(const f16* video_m11, f16* patches, int T, int H, int W, int S224, int P, int Kpad,
-                          hipStream_t s) {
+                          hipStream_t s, int imagenet_norm) {
+  const Norm3 nm = imagenet_norm ? Norm3{{0.485f, 0.456f, 0.406f}, {0.229f, 0.224f, 0.225f}}
+                                 : Norm3{{0.48145466f, 0.4578275f, 0.40821073f}, {0.26862954f, 0.26130258f, 0.27577711f}};
   BlurTaps bt;
   gauss_taps(H, S224, bt.ky, bt.gy);
   gauss_taps(W, S224, bt.kx, bt.gx);
   hipLaunchKernelGGL(k_clip_patchify, gs_grid((long)T * S224 * S224), dim3(256), 0, s, video_m11, patches, T, H, W,
-                     S224, P, Kpad, bt);
+                     S224, P, Kpad, bt, nm);
+}
+
+// ---- StableNormal glue ----
+__global__ void k_scale_rows(f16* w, const f16* gamma, long n, int K) {
+  GS_LOOP(i, n) { w[i] = (f16)((float)w[i] * (float)gamma[i / K]); }
+}
+void launch_scale_rows(f16* w, const f16* gamma, int N, int K, hipStream_t s) {
+  hipLaunchKernelGGL(k_scale_rows, gs_grid((long)N * K), dim3(256), 0, s, w, gamma, (long)N * K, K);
+}
+__global__ void k_add_grid_nearest(f16* x, const f16* grid, int B, int h, int w, int g, int C) {
+  const long n = (long)B * h * w * (C / 8);
+  GS_LOOP(i, n) {
+    const int cv = i % (C / 8); const long pix = i / (C / 8);
+    const int xx = pix % w, yy = (pix / w) % h; const long b = pix / ((long)w * h);
+    const f16x8 a = *(const f16x8*)(x + pix * C + cv * 8);
+    const f16x8 gvec = *(const f16x8*)(grid + ((b * g + (yy * g) / h) * g + (xx * g) / w) * C + cv * 8);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f16)((float)a[e] + (float)gvec[e]);
+    *(f16x8*)(x + pix * C + cv * 8) = o;
+  }
+}
+void launch_add_grid_nearest(f16* x, const f16* grid, int B, int h, int w, int g, int C, hipStream_t s) {
+  hipLaunchKernelGGL(k_add_grid_nearest, gs_grid((long)B * h * w * (C / 8)), dim3(256), 0, s, x, grid, B, h, w, g, C);
+}
+__global__ void k_sn_normals_out(const f16* dec, int ldd, float* out, long pixels) {
+  GS_LOOP(p, pixels) {
+    float v[3]; float n2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { v[c] = fminf(fmaxf((float)dec[p * ldd + c], -1.f), 1.f); n2 += v[c] * v[c]; }
+    const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-6f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[p * 3 + c] = v[c] * inv;
+  }
+}
+void launch_sn_normals_out(const f16* dec, int ldd, float* out, long pixels, hipStream_t s) {
+  hipLaunchKernelGGL(k_sn_normals_out, gs_grid(pixels), dim3(256), 0, s, dec, ldd, out, pixels);
 }
 
 // noise f32 [T,4,h,w] (NCHW, as torch.randn would lay it out) -> latents f16 [T,h,w,4] * sigma0

@@ -246,6 +246,10 @@ def random_state(manifest, seed: int, dtype=np.float16) -> Dict[str, np.ndarray]
     for name, shape in manifest.items():
         if name.endswith("mix_factor"):
             a = rng.normal(0, 0.5, shape)
+        elif name.endswith(".gamma"):                       # DINOv2 LayerScale
+            a = 0.5 + 0.1 * rng.standard_normal(shape)
+        elif name in ("cls_token", "pos_embed"):
+            a = (0.5 if name == "cls_token" else 0.1) * rng.standard_normal(shape)
         elif len(shape) == 1:
             is_gain = name.endswith(".weight")
             a = (1.0 + 0.1 * rng.standard_normal(shape)) if is_gain else 0.05 * rng.standard_normal(shape)
@@ -306,3 +310,193 @@ def load_pretrained(unet_path: str, pre_train_path: str):
     check_against_manifest(v, vae_manifest(), "VAE")
     check_against_manifest(c, clip_manifest(), "CLIP image encoder")
     return u, v, c
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# StableNormal (BASELINE configs[3]; reference model/stablenormal.py:16 loads it through torch.hub - un-vendored).
+# Restated components (oracle/stablenormal.py, DESIGN.md "StableNormal uncertainty register"): SD-2.1-class UNet2DConditionModel
+# x 2 (YOSO one-step + refinement), ControlNet trunk x 2 (image-latent + DINO-guided), SD AutoencoderKL, DINOv2 ViT-L/14.
+# ------------------------------------------------------------------------------------------------------------------
+@dataclass
+class SDUNetCfg:
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    layers_per_block: int = 2
+    num_attention_heads: Tuple[int, ...] = (5, 10, 20, 20)
+    cross_attention_dim: int = 1024
+    norm_groups: int = 32
+    down_has_attn: Tuple[bool, ...] = (True, True, True, False)
+
+
+@dataclass
+class DinoCfg:
+    hidden_size: int = 1024
+    intermediate_size: int = 4096
+    num_hidden_layers: int = 24
+    num_attention_heads: int = 16
+    image_size: int = 224
+    patch_size: int = 14
+    layer_norm_eps: float = 1e-6
+
+
+def tiny_sn_cfgs():
+    """Small StableNormal configuration with the full topology (every block type of both UNets, both ControlNets, the 2-D VAE
+    decoder and the DINO tower) for parity tests the CPU oracle finishes in seconds."""
+    u = SDUNetCfg(block_out_channels=(64, 128, 128, 128), num_attention_heads=(1, 2, 2, 2), cross_attention_dim=48, norm_groups=16)
+    v = VAECfg(block_out_channels=(32, 64, 64, 64), norm_groups=8)
+    d = DinoCfg(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=1)
+    return u, v, d
+
+
+def _sd_transformer(m, p, ch, cross):
+    m.norm(p + ".norm", ch); m.lin(p + ".proj_in", ch, ch)
+    b = p + ".transformer_blocks.0"
+    m.norm(b + ".norm1", ch); _attn(m, b + ".attn1", ch, ch)
+    m.norm(b + ".norm2", ch); _attn(m, b + ".attn2", ch, ch, cross)
+    m.norm(b + ".norm3", ch); _ff(m, b + ".ff", ch)
+    m.lin(p + ".proj_out", ch, ch)
+
+
+def _sd_res(m, p, cin, cout, temb):
+    m.norm(p + ".norm1", cin); m.conv2(p + ".conv1", cin, cout)
+    m.lin(p + ".time_emb_proj", temb, cout)
+    m.norm(p + ".norm2", cout); m.conv2(p + ".conv2", cout, cout)
+    if cin != cout:
+        m.conv2(p + ".conv_shortcut", cin, cout, k=1)
+
+
+def _sd_trunk(m, cfg):
+    boc = cfg.block_out_channels
+    n, temb, x = len(boc), boc[0] * 4, cfg.cross_attention_dim
+    m.conv2("conv_in", cfg.in_channels, boc[0])
+    m.lin("time_embedding.linear_1", boc[0], temb); m.lin("time_embedding.linear_2", temb, temb)
+    ch = boc[0]
+    for i in range(n):
+        for j in range(cfg.layers_per_block):
+            _sd_res(m, f"down_blocks.{i}.resnets.{j}", ch if j == 0 else boc[i], boc[i], temb)
+            if cfg.down_has_attn[i]:
+                _sd_transformer(m, f"down_blocks.{i}.attentions.{j}", boc[i], x)
+        if i != n - 1:
+            m.conv2(f"down_blocks.{i}.downsamplers.0.conv", boc[i], boc[i])
+        ch = boc[i]
+    _sd_res(m, "mid_block.resnets.0", boc[-1], boc[-1], temb)
+    _sd_transformer(m, "mid_block.attentions.0", boc[-1], x)
+    _sd_res(m, "mid_block.resnets.1", boc[-1], boc[-1], temb)
+
+
+def sd_unet_manifest(cfg: SDUNetCfg = SDUNetCfg()) -> "OrderedDict[str, tuple]":
+    """diffusers UNet2DConditionModel (SD 2.1): 865 910 724 parameters at the default configuration."""
+    m = _M()
+    _sd_trunk(m, cfg)
+    boc = cfg.block_out_channels
+    n, temb, x = len(boc), boc[0] * 4, cfg.cross_attention_dim
+    rev, rattn = list(reversed(boc)), list(reversed(cfg.down_has_attn))
+    out, L = rev[0], cfg.layers_per_block + 1
+    for i in range(n):
+        prev, out = out, rev[i]
+        cin = rev[min(i + 1, n - 1)]
+        for j in range(L):
+            _sd_res(m, f"up_blocks.{i}.resnets.{j}", (prev if j == 0 else out) + (cin if j == L - 1 else out), out, temb)
+            if rattn[i]:
+                _sd_transformer(m, f"up_blocks.{i}.attentions.{j}", out, x)
+        if i != n - 1:
+            m.conv2(f"up_blocks.{i}.upsamplers.0.conv", out, out)
+    m.norm("conv_norm_out", boc[0]); m.conv2("conv_out", boc[0], cfg.out_channels)
+    return m
+
+
+def controlnet_manifest(cfg: SDUNetCfg = SDUNetCfg(), dino_dim: int = 0) -> "OrderedDict[str, tuple]":
+    """diffusers ControlNetModel trunk + zero convs; the image latent is its `sample` (no pixel-space conditioning stem); the DINO
+    variant carries `dino_controlnet_cond_embedding` (Linear dino_dim -> conv_in width)."""
+    m = _M()
+    _sd_trunk(m, cfg)
+    boc = cfg.block_out_channels
+    chans = [boc[0]]
+    for i, c in enumerate(boc):
+        chans += [c] * cfg.layers_per_block + ([c] if i != len(boc) - 1 else [])
+    for k, c in enumerate(chans):
+        m.conv2(f"controlnet_down_blocks.{k}", c, c, k=1)
+    m.conv2("controlnet_mid_block", boc[-1], boc[-1], k=1)
+    if dino_dim:
+        m.lin("dino_controlnet_cond_embedding", dino_dim, boc[0])
+    return m
+
+
+def sd_vae_manifest(cfg: VAECfg = VAECfg()) -> "OrderedDict[str, tuple]":
+    """diffusers AutoencoderKL (SD): the encoder of vae_manifest + the plain 2-D decoder + quant / post_quant convs (83 653 863 parameters)."""
+    m = _M()
+    full = vae_manifest(cfg)
+    for k, v in full.items():
+        if k.startswith("encoder.") or k.startswith("quant_conv"):
+            m[k] = v
+    boc, L = cfg.block_out_channels, cfg.layers_per_block
+    m.conv2("post_quant_conv", cfg.latent_channels, cfg.latent_channels, k=1)
+    m.conv2("decoder.conv_in", cfg.latent_channels, boc[-1])
+    _res2d(m, "decoder.mid_block.resnets.0", boc[-1], boc[-1])
+    _vae_attn(m, "decoder.mid_block.attentions.0", boc[-1])
+    _res2d(m, "decoder.mid_block.resnets.1", boc[-1], boc[-1])
+    rev, out = list(reversed(boc)), boc[-1]
+    for i in range(len(boc)):
+        prev, out = out, rev[i]
+        for j in range(L + 1):
+            _res2d(m, f"decoder.up_blocks.{i}.resnets.{j}", prev if j == 0 else out, out)
+        if i != len(boc) - 1:
+            m.conv2(f"decoder.up_blocks.{i}.upsamplers.0.conv", out, out)
+    m.norm("decoder.conv_norm_out", boc[0]); m.conv2("decoder.conv_out", boc[0], cfg.out_channels)
+    return m
+
+
+def dino_manifest(cfg: DinoCfg = DinoCfg()) -> "OrderedDict[str, tuple]":
+    """dinov2 hub naming (ViT-L/14 + LayerScale); pos_embed is held at the tower's own grid (image_size / patch_size)^2 + 1 -
+    a checkpoint's 37x37 table is resampled by load_stablenormal_pretrained."""
+    m = _M()
+    d, g = cfg.hidden_size, cfg.image_size // cfg.patch_size
+    m["cls_token"] = (1, 1, d)
+    m["pos_embed"] = (1, 1 + g * g, d)
+    m["patch_embed.proj.weight"] = (d, 3, cfg.patch_size, cfg.patch_size); m["patch_embed.proj.bias"] = (d,)
+    for i in range(cfg.num_hidden_layers):
+        p = f"blocks.{i}"
+        m.norm(p + ".norm1", d); m.lin(p + ".attn.qkv", d, 3 * d); m.lin(p + ".attn.proj", d, d); m[p + ".ls1.gamma"] = (d,)
+        m.norm(p + ".norm2", d); m.lin(p + ".mlp.fc1", d, cfg.intermediate_size); m.lin(p + ".mlp.fc2", cfg.intermediate_size, d)
+        m[p + ".ls2.gamma"] = (d,)
+    m.norm("norm", d)
+    return m
+
+
+def load_stablenormal_pretrained(model_dir: str):
+    """Checkpoint directory -> ({component: state}, prompt_embeds [77,1024]).  Expected layout (diffusers-style, one sub-directory per
+    component; S11): ``vae/``, ``unet_yoso/``, ``controlnet_yoso/``, ``unet/``, ``controlnet_dino/`` each with
+    ``diffusion_pytorch_model[.fp16].safetensors``; ``dino/model.safetensors`` (dinov2 hub naming); ``text_encoder/`` + ``tokenizer/``
+    (transformers CLIPTextModel - run ONCE here, on the host, for the fixed prompt) or a precomputed ``prompt_embeds.npy``.
+    Every state dict is checked against the manifest; DINO's 37x37 position table is resampled (bicubic) to the tower's grid."""
+    cfgs = (SDUNetCfg(), VAECfg(), DinoCfg())
+    names = ["diffusion_pytorch_model.fp16.safetensors", "diffusion_pytorch_model.safetensors", "model.fp16.safetensors", "model.safetensors"]
+    man = {"vae": sd_vae_manifest(cfgs[1]), "unet_yoso": sd_unet_manifest(cfgs[0]), "controlnet_yoso": controlnet_manifest(cfgs[0]),
+           "unet": sd_unet_manifest(cfgs[0]), "controlnet_dino": controlnet_manifest(cfgs[0], cfgs[2].hidden_size), "dino": dino_manifest(cfgs[2])}
+    states = {}
+    for comp, m in man.items():
+        st = load_safetensors(_first_existing(os.path.join(model_dir, comp), names))
+        if comp == "dino":
+            st = {k: v for k, v in st.items() if k != "mask_token"}
+            pe = st["pos_embed"]
+            g_src, g_dst = int(round((pe.shape[1] - 1) ** 0.5)), cfgs[2].image_size // cfgs[2].patch_size
+            if g_src != g_dst:
+                import torch
+                grid = torch.from_numpy(np.asarray(pe[0, 1:], np.float32)).reshape(1, g_src, g_src, -1).permute(0, 3, 1, 2)
+                grid = torch.nn.functional.interpolate(grid, size=(g_dst, g_dst), mode="bicubic", align_corners=False)
+                st["pos_embed"] = np.concatenate([np.asarray(pe[:, :1], np.float32), grid.permute(0, 2, 3, 1).reshape(1, g_dst * g_dst, -1).numpy()], 1)
+        check_against_manifest(st, m, f"StableNormal {comp}")
+        states[comp] = st
+    pe_file = os.path.join(model_dir, "prompt_embeds.npy")
+    if os.path.exists(pe_file):
+        prompt = np.load(pe_file).astype(np.float32).reshape(77, -1)
+    else:
+        import torch
+        from transformers import CLIPTextModel, CLIPTokenizer
+        tok = CLIPTokenizer.from_pretrained(os.path.join(model_dir, "tokenizer"))
+        enc = CLIPTextModel.from_pretrained(os.path.join(model_dir, "text_encoder")).eval()
+        ids = tok("The normal map", padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+        with torch.no_grad():
+            prompt = enc(ids)[0][0].float().numpy()
+    return states, prompt
