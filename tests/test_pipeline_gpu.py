@@ -228,7 +228,7 @@ def test_multi_gpu_entry_points_run_under_a_single_rank_rccl_group(tmp_path):
                         "--frames", "5", "--height", "64", "--width", "128", "--denoise-steps", "2", "--no-cpu-baseline"],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    line = json.loads(r.stdout.strip().splitlines()[-1])          # the JSON line must be the LAST line of stdout (driver contract)
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak" and "all_gather" in line["config"]["parallelism"]
     cfg = tmp_path / "cfg.yaml"
     cfg.write_text(textwrap.dedent("""

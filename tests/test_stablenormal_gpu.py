@@ -43,7 +43,7 @@ def test_dino_tokens(tiny):
     got = tiny["eng"].sn_dino(img)
     with torch.no_grad():
         ref = tiny["dino"](dino_preprocess(torch.from_numpy(img).permute(0, 3, 1, 2) * 2 - 1, 224)).numpy()
-    assert_close(got, ref, 6e-3, "SN tiny DINO patch tokens")
+    assert_close(got, ref, 2e-3, "SN tiny DINO patch tokens")
 
 
 def test_sd_vae(tiny):
@@ -51,11 +51,11 @@ def test_sd_vae(tiny):
     img = h16(rng.uniform(-1, 1, (2, 64, 64, 3)))
     with torch.no_grad():
         ref_e = tiny["vae"].encode_mode(torch.from_numpy(img).permute(0, 3, 1, 2)).numpy()
-    assert_close(tiny["eng"].sn_vae_encode(img), ref_e, 5e-3, "SN tiny VAE encode (fp16 storage)")
+    assert_close(tiny["eng"].sn_vae_encode(img), ref_e, 3.5e-3, "SN tiny VAE encode (fp16 storage)")
     z = h16(rng.standard_normal((2, 4, 8, 16)) * 2)
     with torch.no_grad():
         ref_d = tiny["vae"].decode(torch.from_numpy(z)).permute(0, 2, 3, 1).numpy()
-    assert_close(tiny["eng"].sn_vae_decode(z), ref_d, 6e-3, "SN tiny VAE 2-D decode")
+    assert_close(tiny["eng"].sn_vae_decode(z), ref_d, 4e-3, "SN tiny VAE 2-D decode")
 
 
 @pytest.mark.parametrize("which,use_ctrl", [(0, False), (0, True), (1, True)])
@@ -74,7 +74,7 @@ def test_unet_with_controlnet(tiny, which, use_ctrl):
         if use_ctrl:
             dr, mr = ctrl(torch.from_numpy(z), t_c, ctx, **({"dino_tokens": torch.from_numpy(tok)} if which == 1 else {}))
         ref = unet(torch.from_numpy(x), t_u, ctx, dr, mr).numpy()
-    assert_close(got, ref, 6e-3, f"SN tiny UNet which={which} ctrl={use_ctrl}")
+    assert_close(got, ref, 4e-3, f"SN tiny UNet which={which} ctrl={use_ctrl}")
 
 
 @pytest.mark.parametrize("B,H,W", [(1, 64, 64), (3, 64, 128)])
@@ -135,7 +135,7 @@ def test_full_architecture_unet_controlnet_and_576_image():
         with torch.no_grad():
             dr, mr = o["ctrl_d"](torch.from_numpy(z), 0.0, ctx, dino_tokens=torch.from_numpy(tok))
             ref = o["unet_r"](torch.from_numpy(x), 281.0, ctx, dr, mr).numpy()
-        assert_close(got, ref, 6e-3, "SN full-architecture UNet + DINO ControlNet")
+        assert_close(got, ref, 4.5e-3, "SN full-architecture UNet + DINO ControlNet")
         yy, xx = np.mgrid[0:576, 0:576].astype(np.float32)
         img = np.stack([127.5 + 100 * np.sin(xx / 41.0 + c) * np.cos(yy / 29.0) for c in range(3)], -1) + rng.normal(0, 8, (576, 576, 3))
         img = (np.clip(img, 0, 255).astype(np.uint8).astype(np.float32) / 255.0)[None]
