@@ -97,6 +97,11 @@ int ug_dc_get_outputs(ug_ctx* ctx, float* frames_out, float* depth_out, float* n
  * fp32 residual stream / GroupNorm / softmax, GEMMs on fp16 hi/lo activation pairs against the (fp16-valued) weights, which is
  * exact to fp32 rounding.  on = 0: fp16 storage with fp32 accumulation, like the decoder (faster, ~1e-3 off the fp32 result). */
 int ug_set_vae_encode_fp32(ug_ctx* ctx, int on);
+/* BASELINE configs[4] (north_star: "fp8 MFMA ... (CDNA4 fp8)"): on = 1 runs the UNet transformers' linear layers whose K is a multiple
+ * of 128 on MX-fp8 matrix instructions (v_mfma_scale_f32_16x16x128_f8f6f4: OCP e4m3 elements, one e8m0 power-of-two scale per 32
+ * K elements; activations are quantised on the fly, weights once at bind time).  Reduced precision - the reference has no fp8 path;
+ * the measured error against the fp16 path and the oracle is reported by tests/test_fp8_gpu.py.  Default 0. */
+int ug_set_fp8_linears(ug_ctx* ctx, int on);
 /* Parity instrumentation (no reference counterpart; the reference would use the pipeline's callback_on_step_end): while
  * host_latents != NULL, ug_dc_run copies the latents after each of the first `steps` Euler steps to
  * host_latents[step][T][h][w][4] (float32, channels-last).  NULL switches it off.  Costs one host sync per step. */
@@ -151,6 +156,10 @@ int ug_eval_normal(ug_ctx* ctx, const float* pred_normals, const float* gt_norma
 /* Op-level entry points for kernel parity tests (row-major host matrices, fp32 in/out, computed in fp16). */
 int ug_op_linear(ug_ctx* ctx, const float* A, int M, int K, const float* W, int N, const float* bias,
                  const float* R1, float c0, float c1, int act, int geglu, float* out);
+/* MX-fp8 linear: A [M,K], W [N,K] are quantised on device (kernels/mx8.hip) and multiplied on the fp8 matrix cores; optional outputs:
+ * the quantised A bytes [M,K] and its scale dwords [K/128][round_up(M,256)] (4 e8m0 per dword) for bit-level checks. */
+int ug_op_linear_mx8(ug_ctx* ctx, const float* A, int M, int K, const float* W, int N, const float* bias, int geglu, float* out,
+                     unsigned char* a8_out, unsigned* scales_out);
 int ug_op_conv(ug_ctx* ctx, const float* x0_thwc, int C0, const float* x1_thwc, int C1, int T, int H, int W,
                const float* weight /*[O][I][kt][ky][kx]*/, const float* bias, int O, int kt, int k, int stride,
                int pad_t, int pad_l, int ups, float* out_thwc);

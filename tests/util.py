@@ -48,3 +48,38 @@ def report(name, value, **extra):
     except OSError:
         pass
     return float(value)
+
+
+def e4m3_rne(y):
+    """float -> nearest OCP e4m3 value (round-to-nearest-even, saturating at +-448), returned as float32."""
+    y = np.asarray(y, dtype=np.float64)
+    a = np.minimum(np.abs(y), 448.0)
+    ex = np.floor(np.log2(np.maximum(a, 2.0 ** -20)))
+    ex = np.maximum(ex, -6.0)                                   # subnormals share the quantum of the smallest normal binade
+    quantum = 2.0 ** (ex - 3)
+    q = np.rint(a / quantum) * quantum                          # np.rint = half-to-even
+    return (np.sign(y) * np.minimum(q, 448.0)).astype(np.float32)
+
+
+def e4m3_encode(v):
+    """e4m3 value (as produced by e4m3_rne) -> byte."""
+    v = np.asarray(v, dtype=np.float64)
+    a = np.abs(v)
+    ex = np.floor(np.log2(np.maximum(a, 2.0 ** -20))).astype(np.int64)
+    normal = a >= 2.0 ** -6
+    e = np.where(normal, ex + 7, 0)
+    m = np.where(normal, np.rint((a / 2.0 ** np.where(normal, ex, 0) - 1.0) * 8), np.rint(a / 2.0 ** -9)).astype(np.int64)
+    return ((np.signbit(v).astype(np.int64) << 7) | (e << 3) | m).astype(np.uint8)
+
+
+def mx8_quantise(x):
+    """OCP-MX fp8 quantisation as kernels/mx8.hip does it: x [M,K] -> (dequantised float32 [M,K], bytes [M,K], biased e8m0 [M,K/32])."""
+    x = np.asarray(x, dtype=np.float32)
+    M, K = x.shape
+    xb = x.reshape(M, K // 32, 32).astype(np.float64)
+    amax = np.abs(xb).max(-1)
+    ex = np.where(amax > 0, np.floor(np.log2(np.maximum(amax, 1e-300))) - 8, 0.0)
+    ex = np.clip(ex, -127, 127)
+    q = e4m3_rne(xb * 2.0 ** (-ex[..., None]))
+    deq = (q.astype(np.float64) * 2.0 ** ex[..., None]).reshape(M, K).astype(np.float32)
+    return deq, e4m3_encode(q).reshape(M, K), (ex + 127).astype(np.uint8)

@@ -44,6 +44,12 @@ int main() {
   hipMalloc(&dA, A.size()); hipMalloc(&dB, B.size()); hipMalloc(&dSA, 64); hipMalloc(&dSB, 64); hipMalloc(&dC, 1024);
   hipMemcpy(dA, A.data(), A.size(), hipMemcpyHostToDevice); hipMemcpy(dB, B.data(), B.size(), hipMemcpyHostToDevice);
   hipMemcpy(dSA, SA.data(), 64, hipMemcpyHostToDevice); hipMemcpy(dSB, SB.data(), 64, hipMemcpyHostToDevice);
+  for (int pass = 0; pass < 2; ++pass) {
+  if (pass == 1) {   // unit scales: what is left is the instruction's own accumulation error
+    for (auto& x : SA) x = 127; for (auto& x : SB) x = 127;
+    hipMemcpy(dSA, SA.data(), 64, hipMemcpyHostToDevice); hipMemcpy(dSB, SB.data(), 64, hipMemcpyHostToDevice);
+    printf("-- all block scales = 2^0 --\n");
+  }
   for (int hyp = 0; hyp < 2; ++hyp) {
     hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, dA, dB, dSA, dSB, dC, hyp);
     float C[256]; hipMemcpy(C, dC, 1024, hipMemcpyDeviceToHost);
@@ -59,6 +65,7 @@ int main() {
       }
       printf("hyp %d (K %s), C %s: max err %.4g (max |C| %.4g)\n", hyp, hyp ? "16+16 split" : "32 contiguous", tr ? "= (A B^T)^T" : "= A B^T", worst, mag);
     }
+  }
   }
   return 0;
 }

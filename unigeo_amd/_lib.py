@@ -18,7 +18,7 @@ EXPORTS = [
     "ug_unet_config_default", "ug_vae_config_default", "ug_clip_config_default",
     "ug_create", "ug_destroy", "ug_last_error", "ug_workspace_peak",
     "ug_load_tensor", "ug_bind_unet", "ug_bind_vae", "ug_bind_clip",
-    "ug_dc_set_inputs", "ug_dc_run", "ug_dc_run_windows", "ug_dc_get_outputs", "ug_dc_device_ptrs", "ug_dc_set_trace", "ug_set_vae_encode_fp32",
+    "ug_dc_set_inputs", "ug_dc_run", "ug_dc_run_windows", "ug_dc_get_outputs", "ug_dc_device_ptrs", "ug_dc_set_trace", "ug_set_vae_encode_fp32", "ug_set_fp8_linears", "ug_op_linear_mx8",
     "ug_eval_depth", "ug_eval_normal", "ug_clip_embed", "ug_vae_encode", "ug_vae_decode", "ug_unet_forward", "ug_normals_from_depth",
     "ug_op_linear", "ug_op_conv", "ug_op_groupnorm", "ug_op_layernorm", "ug_op_flash_attn",
     "ug_op_temporal_attn", "ug_op_attention_generic", "ug_op_euler_step",
@@ -81,6 +81,8 @@ def load_library():
     lib.ug_dc_get_outputs.argtypes = [vp, vp, vp, vp]
     lib.ug_dc_set_trace.argtypes = [vp, vp, ip]
     lib.ug_set_vae_encode_fp32.argtypes = [vp, ip]
+    lib.ug_set_fp8_linears.argtypes = [vp, ip]
+    lib.ug_op_linear_mx8.argtypes = [vp, vp, ip, ip, vp, ip, vp, ip, vp, vp, vp]
     lib.ug_dc_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.ug_eval_depth.argtypes = [vp, vp, vp, vp, C.c_long, C.c_float, vp]
     lib.ug_eval_normal.argtypes = [vp, vp, vp, vp, C.c_long, vp]
@@ -273,6 +275,19 @@ class Engine:
     def set_vae_encode_fp32(self, on=True):
         """True (default) = the reference's float32 VAE encoder (force_upcast); False = fp16 storage like the decoder."""
         self._ck(self.lib.ug_set_vae_encode_fp32(self.ctx, int(bool(on))))
+
+    def set_fp8_linears(self, on=True):
+        """MX-fp8 matrix instructions for the UNet transformers' linear layers (BASELINE configs[4]); reduced precision, default off."""
+        self._ck(self.lib.ug_set_fp8_linears(self.ctx, int(bool(on))))
+
+    def op_linear_mx8(self, A, W, bias=None, geglu=False, return_quant=False):
+        A, W = _f32(A), _f32(W); M, K = A.shape; N = W.shape[0]
+        b = None if bias is None else _f32(bias)
+        out = np.empty((M, N // 2 if geglu else N), np.float32)
+        a8 = np.empty((M, K), np.uint8) if return_quant else None
+        sa = np.empty((K // 128, (M + 255) // 256 * 256), np.uint32) if return_quant else None
+        self._ck(self.lib.ug_op_linear_mx8(self.ctx, _ptr(A), M, K, _ptr(W), N, _ptr(b), int(bool(geglu)), _ptr(out), _ptr(a8), _ptr(sa)))
+        return (out, a8, sa) if return_quant else out
 
     def run_traced(self, steps, decode_chunk=8, with_normals=False):
         """ug_dc_run with the latents after every Euler step copied out: returns [steps, T, 4, h, w] float32."""

@@ -121,6 +121,11 @@ int ug_dc_run(ug_ctx* x, int steps, int chunk, int with_normals) { UG_TRY(x, dc_
 int ug_dc_run_windows(ug_ctx* x, int steps, int chunk, int with_normals, int window, int overlap) {
   UG_TRY(x, dc_run(x->c, steps, chunk, with_normals, window, overlap));
 }
+int ug_set_fp8_linears(ug_ctx* x, int on) {
+  if (!x) return -1;
+  x->c.fp8_linears = on ? 1 : 0;
+  return 0;
+}
 int ug_set_vae_encode_fp32(ug_ctx* x, int on) {
   if (!x) return -1;
   x->c.vae_encode_fp32 = on ? 1 : 0;
@@ -454,6 +459,45 @@ int ug_op_linear(ug_ctx* x, const float* A, int M, int K, const float* W, int N,
     { int cf, sp; gemm_plan(p, 1, &cf, &sp); p.cfg_p1 = cf + 1; p.splitk = sp; if (sp > 1) p.partial = c.ws.get<float>((long)sp * M * N); }
     launch_gemm(p, 1, c.stream);
     down16(c, dO, out, (long)M * Nout);
+  });
+}
+
+int ug_op_linear_mx8(ug_ctx* x, const float* A, int M, int K, const float* W, int N, const float* bias, int geglu, float* out,
+                     unsigned char* a8_out, unsigned* sa_out) {
+  UG_TRY(x, {
+    Ctx& c = x->c; Scope sc(c);
+    UG_REQUIRE(K % 128 == 0 && N % 8 == 0, "op_linear_mx8: K % 128 == 0, N % 8 == 0");
+    f16* dA = up16(c, A, (long)M * K); f16* dW = up16(c, W, (long)N * K);
+    f16* db = up16_opt(c, bias, N);
+    const long ld_sa = (M + 255) / 256 * 256, ld_sw = (N + 255) / 256 * 256;
+    unsigned char* a8 = (unsigned char*)c.ws.alloc((size_t)M * K); unsigned char* w8 = (unsigned char*)c.ws.alloc((size_t)N * K);
+    unsigned* sa = (unsigned*)c.ws.alloc((size_t)(K / 128) * ld_sa * 4); unsigned* sw = (unsigned*)c.ws.alloc((size_t)(K / 128) * ld_sw * 4);
+    UG_CHECK(hipMemsetAsync(sa, 0, (size_t)(K / 128) * ld_sa * 4, c.stream)); UG_CHECK(hipMemsetAsync(sw, 0, (size_t)(K / 128) * ld_sw * 4, c.stream));
+    f16* dW2 = dW;
+    if (geglu) {   // the engine's GEGLU row order: blocks of 16 rows = [8 value | 8 gate]
+      std::vector<f16> hw((size_t)N * K), hb(N);
+      const int inner = N / 2;
+      for (int v = 0; v < N; ++v) {
+        const int blk = v / 16, wv = v % 16, srcr = wv < 8 ? blk * 8 + wv : inner + blk * 8 + (wv - 8);
+        for (int k = 0; k < K; ++k) hw[(size_t)v * K + k] = (f16)W[(size_t)srcr * K + k];
+        hb[v] = bias ? (f16)bias[srcr] : (f16)0.f;
+      }
+      dW2 = c.ws.get<f16>((long)N * K);
+      UG_CHECK(hipMemcpy(dW2, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+      if (bias) UG_CHECK(hipMemcpy(db, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
+    }
+    launch_quant_mx8(dA, K, M, K, a8, sa, ld_sa, c.stream);
+    launch_quant_mx8(dW2, K, N, K, w8, sw, ld_sw, c.stream);
+    const int nout = geglu ? N / 2 : N;
+    f16* dO = c.ws.get<f16>((long)M * nout);
+    GemmP p; memset(&p, 0, sizeof(p));
+    p.A0 = (const f16*)a8; p.C0 = K; p.M = M; p.N = N; p.K = K; p.W = (const f16*)w8; p.ldw = K; p.bias = db; p.c0 = 1.f;
+    p.Out = dO; p.ldo = nout; p.flags = geglu ? UG_F_GEGLU : 0; p.zero = c.zero; p.nb_inner = 1;
+    p.sa = sa; p.ld_sa = ld_sa; p.sw = sw; p.ld_sw = ld_sw;
+    launch_gemm_mx8(p, c.stream);
+    down16(c, dO, out, (long)M * nout);
+    if (a8_out) UG_CHECK(hipMemcpy(a8_out, a8, (size_t)M * K, hipMemcpyDeviceToHost));
+    if (sa_out) UG_CHECK(hipMemcpy(sa_out, sa, (size_t)(K / 128) * ld_sa * 4, hipMemcpyDeviceToHost));
   });
 }
 

@@ -66,7 +66,13 @@ struct GemmP {
   float* partial;        // split-K scratch: splitk * M * N floats
   void* trace;           // UG_GEMM_TRACE builds only: cycle-stamp dump (tools/gemm_trace.py)
   int up_phase;          // 0 = off; 1 + (a*2+b): conv output row (t,y,x) is stored at row (t, 2y+a, 2x+b) of a 2Ho x 2Wo grid
+  // MX-fp8 dense path (launch_gemm_mx8): A0 / W point at OCP e4m3 bytes ([M][K] / [N][K], K % 128 == 0); sa / sw hold the e8m0 block
+  // scales, four per dword (K blocks of 32 inside one 128-wide K step), K-step-major: sa[kstep * ld_sa + m], sw[kstep * ld_sw + n]
+  const unsigned* sa; const unsigned* sw; long ld_sa, ld_sw;
 };
+void launch_gemm_mx8(const GemmP& p, hipStream_t s);   // dense only; C0 = lda and ldw in BYTES (= elements)
+// fp16 [M, K] (row stride ldx) -> e4m3 bytes [M, K] + e8m0 scales (layout above, ld_s >= round_up(M, 256)); K % 128 == 0
+void launch_quant_mx8(const f16* x, long ldx, long M, int K, unsigned char* q, unsigned* scales, long ld_s, hipStream_t s);
 void launch_gemm(const GemmP& p, int batch, hipStream_t s);
 void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out);   // heuristic used when cfg/splitk are 0
 void gemm_force(int cfg, int split);                                       // tuning aid: override the heuristic (-1 = off)

@@ -28,7 +28,9 @@ class Arena {
   char* base_ = nullptr; size_t cap_ = 0, off_ = 0, peak_ = 0;
 };
 
-struct Lin { const f16* w = nullptr; const f16* b = nullptr; int in = 0, out = 0; };
+struct Lin { const f16* w = nullptr; const f16* b = nullptr; int in = 0, out = 0;
+             // optional MX-fp8 copy of the weight (kernels/mx8.hip): e4m3 bytes [out][in] + e8m0 block scales [in/128][ld_sw8] dwords
+             const unsigned char* w8 = nullptr; const unsigned* sw8 = nullptr; long ld_sw8 = 0; };
 struct Conv { const f16* w = nullptr; const f16* b = nullptr; int cin = 0, cinp = 0, cout = 0, kt = 1, ky = 1, kx = 1;
               const f16* wphase = nullptr; };   // wphase: 4 x [cout][2*2][cinp] sub-pixel weights of a nearest-2x upsample conv
 struct Norm { const f16* g = nullptr; const f16* b = nullptr; int c = 0; float eps = 1e-5f; };
@@ -140,6 +142,7 @@ struct Ctx {
   size_t io_mark = 0; bool io_ready = false;
   // parity instrumentation: when set, dc_run copies the latents after every Euler step to this host buffer ([steps][T*h*w*4] f32)
   float* trace_host = nullptr; int trace_steps = 0;
+  int fp8_linears = 0;       // 1 = run the UNet's eligible linear layers on MX-fp8 MFMAs (BASELINE configs[4]; reduced precision, off by default)
   int vae_encode_fp32 = 1;   // 1 = reference behaviour (float32-grade encoder), 0 = fp16 storage like the decoder
 };
 

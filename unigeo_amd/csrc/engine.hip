@@ -96,10 +96,38 @@ static void run_gemm(Ctx& c, GemmP p, int batch, const char* tag) {
   c.ws.release(mk);
 }
 
+static inline long pad256(long x) { return (x + 255) / 256 * 256; }
 // Out[M, lin.out] = A[M, lin.in] W^T (+bias) ...
 static void linear(Ctx& c, const f16* A, long M, const Lin& l, f16* out, const Epi& e = Epi(), long lda = 0,
                    long ldo = 0) {
   GemmP p; memset(&p, 0, sizeof(p));
+  if (c.fp8_linears && l.w8 && M >= 256 && !(e.flags & UG_F_OUT_F32)) {
+    // MX-fp8 path: quantise the activation rows (32-element blocks, e8m0 scales), then the same persistent GEMM on e4m3 operands
+    const size_t mk = c.ws.mark();
+    const int K = l.in;
+    unsigned char* a8 = (unsigned char*)c.ws.alloc((size_t)M * K);
+    const long ld_sa = pad256(M);
+    unsigned* sa = (unsigned*)c.ws.alloc((size_t)(K / 128) * ld_sa * 4);
+    {
+      ProfScope ps(c, "quant_mx8", 0, (double)M * K * 3.0);
+      launch_quant_mx8(A, lda ? lda : K, M, K, a8, sa, ld_sa, c.stream);
+    }
+    p.A0 = (const f16*)a8; p.C0 = K; p.M = (int)M; p.N = l.out; p.K = K;
+    p.W = (const f16*)l.w8; p.ldw = K; p.bias = l.b; p.bias2 = e.bias2;
+    p.R1 = e.R1; p.ldr1 = e.ldr1; p.c1 = e.c1; p.R2 = e.R2; p.ldr2 = e.ldr2; p.c2 = e.c2; p.c0 = e.c0;
+    p.act = e.act; p.flags = e.flags;
+    const int nout = (e.flags & UG_F_GEGLU) ? l.out / 2 : l.out;
+    p.Out = out; p.ldo = ldo ? ldo : nout;
+    if (p.R1 && !p.ldr1) p.ldr1 = nout;
+    if (p.R2 && !p.ldr2) p.ldr2 = nout;
+    p.sa = sa; p.ld_sa = ld_sa; p.sw = l.sw8; p.ld_sw = l.ld_sw8; p.zero = c.zero; p.nb_inner = 1;
+    {
+      ProfScope ps(c, "gemm_linear_mx8", 2.0 * M * (double)l.out * K, (double)M * K + (double)l.out * K + 2.0 * M * nout);
+      launch_gemm_mx8(p, c.stream);
+    }
+    c.ws.release(mk);
+    return;
+  }
   p.A0 = A; p.C0 = (int)(lda ? lda : l.in); p.M = (int)M; p.N = l.out; p.K = l.in;
   p.W = l.w; p.ldw = l.in; p.bias = l.b; p.bias2 = e.bias2;
   p.R1 = e.R1; p.ldr1 = e.ldr1; p.c1 = e.c1; p.R2 = e.R2; p.ldr2 = e.ldr2; p.c2 = e.c2; p.c0 = e.c0;
@@ -280,6 +308,16 @@ static Lin bind_geglu(Ctx& c, const std::string& p, int in, int inner) {
   return l;
 }
 static inline int pad8(int x) { return (x + 7) & ~7; }
+// MX-fp8 copy of a bound linear layer's weight (rows are quantised independently along K, so fused / re-ordered rows stay valid)
+static void quant_lin(Ctx& c, Lin& l) {
+  if (l.in % 128 != 0 || l.out < 64) return;
+  unsigned char* w8 = (unsigned char*)c.persist.alloc((size_t)l.out * l.in);
+  const long ld = pad256(l.out);
+  unsigned* sw = (unsigned*)c.persist.alloc((size_t)(l.in / 128) * ld * 4);
+  UG_CHECK(hipMemsetAsync(sw, 0, (size_t)(l.in / 128) * ld * 4, c.stream));
+  launch_quant_mx8(l.w, l.in, l.out, l.in, w8, sw, ld, c.stream);
+  l.w8 = w8; l.sw8 = sw; l.ld_sw8 = ld;
+}
 // Conv2d [O][I][k][k] -> [O][k*k][Ipad];  Conv3d [O][I][3][1][1] -> [O][3][Ipad]
 static Conv bind_conv(Ctx& c, const std::string& p, int cin, int cout, int kt, int k, bool bias = true, bool upsampler = false) {
   Conv cv; cv.cin = cin; cv.cinp = pad8(cin); cv.cout = cout; cv.kt = kt; cv.ky = k; cv.kx = k;
@@ -397,6 +435,7 @@ static Transformer bind_transformer(Ctx& c, const std::string& p, int C, int hea
   t.tpe2 = bind_lin(c, p + ".time_pos_embed.linear_2", 4 * C, C, true);
   const float mix = raw_scalar(c, p + ".time_mixer.mix_factor");
   t.alpha = 1.f / (1.f + expf(-mix));
+  for (Lin* l : {&t.proj_in, &t.proj_out, &t.qkv1, &t.o1, &t.ff1, &t.ff2, &t.ffin1, &t.ffin2, &t.tqkv, &t.to1, &t.tff1, &t.tff2}) quant_lin(c, *l);
   return t;
 }
 

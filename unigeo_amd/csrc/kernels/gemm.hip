@@ -237,9 +237,14 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][N
 // SQ_ACTIVE_INST_VALU that address arithmetic was ~1/4 of a K-step on the 8-wave tiles and more on the small ones.
 // Requires 32-bit offsets (operands < 2 GiB), whole K tiles (dense K % BK == 0) and, for im2col, the single-tap-per-
 // K-tile form without the nearest-2x source mapping; launch_mode checks this and otherwise uses the flat-address form.
-template <int BM, int BN, int BK, int NST, int WMW, int WNW, bool CONV, bool UNI, bool BUFA = false>
+// MX: the operands are OCP e4m3 bytes with e8m0 block scales (v_mfma_scale_f32_16x16x128_f8f6f4, 2x the fp16 MFMA rate).  The
+// loaders are byte movers, so an fp8 [rows][K] matrix is staged exactly like an fp16 [rows][K/2] one (the launcher halves K / lda /
+// ldw): a 128-byte LDS row is one 128-deep K step.  The block scales of a K step (one dword = 4 e8m0 per row) ride the same ring:
+// wave 0 / wave 1 fetch the A / W scale dwords of the tile's rows with one extra 1 KiB direct-to-LDS load each.
+template <int BM, int BN, int BK, int NST, int WMW, int WNW, bool CONV, bool UNI, bool BUFA = false, bool MX = false>
 __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>::wps)) void gemm_kernel(const GemmP p) {
   static_assert(!BUFA || !CONV || UNI, "buffer addressing needs the single-tap K tiles");
+  static_assert(!MX || (!CONV && BK == 64 && BM <= 256 && BN <= 256), "MX path: dense, 128-byte K steps, <= 256 scale rows per operand");
   constexpr unsigned SENT = 0x80000000u;   // == num_records: every lane offset >= SENT reads zeros
   constexpr int NWAVE = WMW * WNW;
   constexpr int WTM = BM / WMW, WTN = BN / WNW;     // wave tile
@@ -311,9 +316,11 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
 #pragma unroll
   for (int j = 0; j < BI; ++j) b_lc[j] = pc ^ swz<BK>((wave * BI + j) * RPI + lrow);
 
+  int ld_m0 = 0, ld_n0 = 0;   // MX: origin of the tile being fetched (scale rows)
   auto setup_tile = [&](int tile) {
     const int tn = tile % ntn, tm = tile / ntn;
     const int m0 = tm * BM, n0 = tn * BN;
+    ld_m0 = m0; ld_n0 = n0;
 #pragma unroll
     for (int j = 0; j < AI; ++j) {
       const int m = m0 + (wave * AI + j) * RPI + lrow;
@@ -440,6 +447,13 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
       }
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (wave * AI + j) * RPI * BK), 16, 0, 0);
     }
+    if (MX && wave < 2) {   // block scales of this K step: 4 rows' dwords per lane -> [BM | BN] dwords behind the operand ring
+      unsigned* sc = (unsigned*)(smem + NST * STAGE) + buf * (BM + BN) + (wave ? BM : 0);
+      const int rows = wave ? BN : BM;
+      const unsigned* g = wave ? p.sw + (long)(kt0 / BK) * p.ld_sw + ld_n0 : p.sa + (long)(kt0 / BK) * p.ld_sa + ld_m0;
+      const void* src = (4 * lane < rows) ? (const void*)(g + 4 * lane) : (const void*)p.zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)sc, 16, 0, 0);
+    }
     if (BUFA) {
 #pragma unroll
       for (int j = 0; j < BI; ++j)
@@ -483,7 +497,10 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
     // wait for the loads of iteration fi (issued NST-1 iterations ago); up to NST-2 younger fetches stay in flight
     const int younger = min(NST - 2, total_it - 1 - fi);
     if (drain || younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
+    else if (MX && wave < 2) {   // these two waves carry one scale load per stage on top
+      if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AI + BI + 1)) : "memory");
+    } else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AI + BI)) : "memory");
     drain = false;
     UG_STAMP(1);   // fetched operands have landed
@@ -494,8 +511,33 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
     UG_STAMP(3);   // next fetch issued
     const f16* Ab = smem + cp_slot * STAGE + (wm * WTM + l15) * BK;
     const f16* Bb = smem + cp_slot * STAGE + BM * BK + (wn * WTN + l15) * BK;
+    const unsigned* scl = (const unsigned*)(smem + NST * STAGE) + cp_slot * (BM + BN);
     if (++cp_slot == NST) cp_slot = 0;
-    {
+    if (MX) {
+      // operand layout of v_mfma_scale_f32_16x16x128_f8f6f4 (measured: tools/microbench/mx8_probe.hip): lane (l15, g) holds K bytes
+      // [16g, 16g+16) in registers 0-3 and [64+16g, 64+16g+16) in registers 4-7 of its row - two stacked 64-deep halves, i.e. the
+      // logical 16-byte chunks g and 4+g - and supplies the e8m0 scale of K block g = K [32g, 32g+32) in byte 0 of the scale operand
+      typedef int v8i __attribute__((ext_vector_type(8)));
+      union Frag { v8i v; f16x8 h[2]; };
+      Frag af[MT], bf[NT];
+      int sA[MT], sW[NT];
+      const int c0 = (g ^ sw) * 8, c1 = ((4 + g) ^ sw) * 8;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        bf[j].h[0] = *(const f16x8*)(Bb + j * 16 * BK + c0); bf[j].h[1] = *(const f16x8*)(Bb + j * 16 * BK + c1);
+        sW[j] = (scl[BM + wn * WTN + (l15 >> 2) * WID + j * 4 + (l15 & 3)] >> (8 * g)) & 0xff;   // LDS row (wn, j, l15) holds this W row
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        af[i].h[0] = *(const f16x8*)(Ab + i * 16 * BK + c0); af[i].h[1] = *(const f16x8*)(Ab + i * 16 * BK + c1);
+        sA[i] = (scl[wm * WTM + i * 16 + l15] >> (8 * g)) & 0xff;
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[j].v, af[i].v, acc[i][j], 0, 0, 0, sW[j], 0, sA[i]);
+    } else {
       // Fragment reads are software-pipelined inside the K-step: all reads of the first 32-deep slice are issued up
       // front, the second slice's reads are interleaved under the first slice's MFMAs (order pinned below), so the
       // LDS latency is exposed once per step instead of once per MFMA group.
@@ -1191,6 +1233,45 @@ static void launch_cfg(int cfg, const GemmP& p, int batch, hipStream_t s) {
 }
 
 static int g_force_cfg = -1, g_force_split = -1, g_knobs = 0;   // knobs: 1 = one tile per workgroup, 2 = no XCD remap, 4 = flat addressing only
+// ---- MX-fp8 dense GEMM (BASELINE configs[4]): the same persistent kernel on e4m3 operands with e8m0 block scales ----
+template <int BM, int BN, int NST, int WMW, int WNW, bool BUFA>
+static void launch_mx_t(const GemmP& p, hipStream_t s) {
+  const int ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
+  const size_t lds = (size_t)NST * (BM + BN) * 64 * sizeof(f16) + (size_t)NST * (BM + BN) * 4;
+  auto kern = gemm_kernel<BM, BN, 64, NST, WMW, WNW, false, false, BUFA, true>;
+  static bool attr = false;
+  if (!attr) { UG_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / lds)));
+  int gx = (per_cu * 256 / 8) * 8;
+  gx = std::min(gx, ntiles);
+  hipLaunchKernelGGL(kern, dim3(gx, 1, 1), dim3(WMW * WNW * 64), lds, s, p);
+}
+template <int BM, int BN, int NST, int WMW, int WNW>
+static void launch_mx(const GemmP& p, hipStream_t s) {
+  const long lim = (1L << 31) - 64;
+  const bool bufa = (long)p.N * p.ldw * 2 < lim && (long)p.M * p.C0 * 2 < lim;
+  if (bufa) launch_mx_t<BM, BN, NST, WMW, WNW, true>(p, s);
+  else launch_mx_t<BM, BN, NST, WMW, WNW, false>(p, s);
+}
+void launch_gemm_mx8(const GemmP& p0, hipStream_t s) {
+  GemmP p = p0;
+  UG_REQUIRE(!p.conv && p.K % 128 == 0 && p.C0 % 16 == 0 && p.ldw % 16 == 0, "MX-fp8 GEMM: dense, K % 128 == 0, 16-byte aligned rows");
+  UG_REQUIRE(p.sa && p.sw && p.zero, "MX-fp8 GEMM needs block scales");
+  UG_REQUIRE(p.M > 0 && p.N > 0 && p.nb_inner >= 1 && p.splitk <= 1, "MX-fp8 GEMM shape");
+  if (p.flags & UG_F_GEGLU) UG_REQUIRE(p.N % 128 == 0, "GEGLU GEMM needs N % 128 == 0");
+  p.K /= 2; p.C0 /= 2; p.ldw /= 2;          // bytes -> the loaders' fp16 units (see gemm_kernel<MX>)
+  p.splitk = 1; p.cfg_p1 = 0;
+  if (g_knobs & 2) p.flags |= UG_F_NOXCD;
+  const int force = g_force_cfg;
+  const int pick = force >= 100 ? force - 100 : (p.M <= 2048 ? 2 : (p.N >= 512 || p.N % 256 == 0) ? 0 : 1);
+  switch (pick) {
+    case 0: launch_mx<256, 256, 2, 2, 4>(p, s); break;
+    case 1: launch_mx<256, 128, 3, 4, 2>(p, s); break;
+    default: launch_mx<128, 128, 2, 2, 2>(p, s); break;
+  }
+  UG_CHECK(hipGetLastError());
+}
+
 void gemm_force(int cfg, int split) { if (cfg <= -100) { g_knobs = -cfg - 100; return; } g_force_cfg = cfg; g_force_split = split; }
 
 
