@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path (RCCL process group, all_gather, barriers, "
                     "max-over-ranks timing) even with one rank - plumbing check for the N > 1 launch on a 1-GPU box")
+    ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4]: run the UNet transformers' linear layers on MX-fp8 matrix instructions "
+                    "(reduced precision; the headline metric is the fp16 path)")
     ap.add_argument("--tiny", action="store_true", help="tiny full-topology weights instead of the 1.5 B-parameter architecture (plumbing checks only)")
     a = ap.parse_args()
     if a.workload == "stablenormal":
@@ -170,6 +172,8 @@ def main():
     else:
         pipe = DepthCrafterPipelineHIP.from_random(seed=42, device_id=local, workspace_bytes=40 << 30)
     eng = pipe.engine
+    if a.fp8:
+        eng.set_fp8_linears(True)
     clip = synthetic_clip(T, H, W, seed=1234 + rank)
     frames = DepthCrafter.prepare_input(None, clip)
     nl, na = make_noise(T, H, W, seed=rank)
@@ -205,9 +209,10 @@ def main():
     if rank == 0:
         ms = dt / a.steps * 1000.0
         value = world * a.steps * T / dt
-        res = {"metric": "frames/sec (384x512, 25-frame clip, 25 denoise steps)", "value": round(value, 3),
+        res = {"metric": f"frames/sec ({H}x{W}, {T}-frame clip, {a.denoise_steps} denoise steps)", "value": round(value, 3),
                "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "fp8 (MX e4m3, e8m0 block scales) linear layers + fp16" if a.fp8 else "fp16",
                "data": "synthetic (seeded frames + noise, seeded random weights of the SVD-XT/DepthCrafter architecture)",
                "config": {"workload": f"DepthCrafter SVD-UNet fp16, {a.denoise_steps}-step Euler, one {T}-frame {H}x{W} clip per GPU "
                                       "(BASELINE configs[1]); CLIP + VAE enc/dec + depth post-proc inside the timed region",
@@ -264,6 +269,10 @@ def main():
             eng.set_vae_encode_fp32(False)
             res["value_fp16_vae_encoder"] = round(rate(2, a.denoise_steps, with_normals=False), 3)
             eng.set_vae_encode_fp32(True)
+            if not a.fp8:
+                eng.set_fp8_linears(True)       # BASELINE configs[4] option: MX-fp8 linear layers (reduced precision; not the headline)
+                res["value_fp8_linears"] = round(rate(2, a.denoise_steps, with_normals=False), 3)
+                eng.set_fp8_linears(False)
             res["vae_encoder"] = "float32-grade (reference force_upcast): fp32 residual stream / norms / softmax, fp16 hi/lo-pair MFMA GEMMs"
         res["workspace_peak_gb"] = round(eng.workspace_peak() / 2 ** 30, 2)
         if not a.no_cpu_baseline and world == 1:

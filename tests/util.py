@@ -58,7 +58,7 @@ def e4m3_rne(y):
     ex = np.maximum(ex, -6.0)                                   # subnormals share the quantum of the smallest normal binade
     quantum = 2.0 ** (ex - 3)
     q = np.rint(a / quantum) * quantum                          # np.rint = half-to-even
-    return (np.sign(y) * np.minimum(q, 448.0)).astype(np.float32)
+    return np.copysign(np.minimum(q, 448.0), y).astype(np.float32)          # -0.0 keeps its sign bit, as the hardware conversion does
 
 
 def e4m3_encode(v):

@@ -451,8 +451,8 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
       unsigned* sc = (unsigned*)(smem + NST * STAGE) + buf * (BM + BN) + (wave ? BM : 0);
       const int rows = wave ? BN : BM;
       const unsigned* g = wave ? p.sw + (long)(kt0 / BK) * p.ld_sw + ld_n0 : p.sa + (long)(kt0 / BK) * p.ld_sa + ld_m0;
-      const void* src = (4 * lane < rows) ? (const void*)(g + 4 * lane) : (const void*)p.zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)sc, 16, 0, 0);
+      // lanes past the tile's rows stay masked off: the 1 KiB image of a full-wave load would run over the neighbouring scale area
+      if (4 * lane < rows) __builtin_amdgcn_global_load_lds((gptr_t)(g + 4 * lane), (lptr_t)sc, 16, 0, 0);
     }
     if (BUFA) {
 #pragma unroll
