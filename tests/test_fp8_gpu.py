@@ -28,7 +28,7 @@ def test_mx8_quantiser_and_gemm(engine, M, K, N):
     e_dev = np.stack([(sa[:, :M] >> (8 * j)) & 0xff for j in range(4)], -1).transpose(1, 0, 2).reshape(M, K // 32)
     np.testing.assert_array_equal(e_dev.astype(np.uint8), e_ref)
     ref = dqa.astype(np.float64) @ dqw.astype(np.float64).T + b
-    assert_close(got, ref, 1.5e-3, f"MX-fp8 GEMM vs exact product of the dequantised operands {M}x{N}x{K}")
+    assert_close(got, ref, 9e-4, f"MX-fp8 GEMM vs exact product of the dequantised operands {M}x{N}x{K}")
     report(f"MX-fp8 linear {M}x{N}x{K}: quantisation error vs the fp16-operand product", rel_err(got, A.astype(np.float64) @ W.T.astype(np.float64) + b))
 
 
@@ -39,7 +39,7 @@ def test_mx8_geglu_epilogue(engine):
     got = engine.op_linear_mx8(A, W, bias=b, geglu=True)
     y = mx8_quantise(A)[0].astype(np.float64) @ mx8_quantise(W)[0].astype(np.float64).T + b
     h, g = torch.from_numpy(y[:, : N // 2]), torch.from_numpy(y[:, N // 2:])
-    assert_close(got, (h * torch.nn.functional.gelu(g)).numpy(), 2e-3, "MX-fp8 GEMM with the GEGLU epilogue")
+    assert_close(got, (h * torch.nn.functional.gelu(g)).numpy(), 7e-4, "MX-fp8 GEMM with the GEGLU epilogue")
 
 
 def test_fp8_unet_error_vs_fp16_path_and_oracle():
@@ -70,7 +70,7 @@ def test_fp8_unet_error_vs_fp16_path_and_oracle():
         e8 = report("UNet (full architecture, 8x32x32): fp8-linear path vs oracle", rel_err(y8, ref))
         report("UNet (full architecture, 8x32x32): fp8-linear path vs fp16 path", rel_err(y8, y16))
         report("UNet (full architecture, 8x32x32): fp8-linear path vs oracle, rms / rms", float(np.sqrt(((y8 - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean())))
-        assert np.isfinite(y8).all() and e16 < 4e-3 and e8 < 8e-2, (e16, e8)
+        assert np.isfinite(y8).all() and e16 < 4e-3 and e8 < 1.2e-1, (e16, e8)      # measured 1.9e-3 / 6.2e-2
     finally:
         pipe.engine.close()
 
@@ -95,6 +95,6 @@ def test_fp8_twin_of_larger_clip_geometry():
         assert np.isfinite(f8).all() and f8.min() >= 0 and f8.max() <= 1 and d8.min() >= 1 / 1.1 - 1e-5 and d8.max() <= 10 + 1e-4
         emax = report("50x576x768, 1 step: fp8-linear frames vs fp16-path frames, max abs", np.abs(f8 - f16_frames).max())
         emean = report("50x576x768, 1 step: fp8-linear frames vs fp16-path frames, mean abs", np.abs(f8 - f16_frames).mean())
-        assert emean < 2e-2 and emax < 0.5, (emean, emax)
+        assert emean < 2e-2 and emax < 0.27, (emean, emax)                             # measured 9.6e-3 / 0.13
     finally:
         pipe.engine.close()

@@ -68,4 +68,4 @@ for (name, N, cv) in convs:
                 r2.append(f"c{c}/s{sp}:{tf:5.0f}")
         print("          split-K:  " + "  ".join(r2))
 ms, tf, c, s = eng.bench_gemm(N=1280, conv=convs[6][2], iters=10)
-print("auto plan for unet1280@6x8:", CFG[c], "split", s, f"{tf:.0f} TF/s")
+print("auto plan for unet1280@6x8:", CFG.get(c, c), "split", s, f"{tf:.0f} TF/s")
