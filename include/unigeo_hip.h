@@ -97,6 +97,12 @@ int ug_dc_get_outputs(ug_ctx* ctx, float* frames_out, float* depth_out, float* n
  * fp32 residual stream / GroupNorm / softmax, GEMMs on fp16 hi/lo activation pairs against the (fp16-valued) weights, which is
  * exact to fp32 rounding.  on = 0: fp16 storage with fp32 accumulation, like the decoder (faster, ~1e-3 off the fp32 result). */
 int ug_set_vae_encode_fp32(ug_ctx* ctx, int on);
+/* Tuning / parity aids for the fused GEGLU feed-forward kernel of the narrow transformer blocks (kernels/ff_fused.hip; the reference's
+ * FeedForward module inside the un-vendored UNet): ug_set_ff_fused(0) falls back to two GEMM launches; ug_op_ff evaluates
+ * c0 * (GEGLU(X W1^T + b1) W2^T + b2) + c1 * R1 on [M, C] with either implementation (W1 [8C][C], b1 [8C], W2 [C][4C] in diffusers order). */
+int ug_set_ff_fused(ug_ctx* ctx, int on);
+int ug_op_ff(ug_ctx* ctx, const float* X, int M, int C, const float* W1, const float* b1, const float* W2, const float* b2, const float* R1,
+             float c0, float c1, int fused, float* out);
 /* BASELINE configs[4] (north_star: "fp8 MFMA ... (CDNA4 fp8)"): on = 1 runs the UNet transformers' linear layers whose K is a multiple
  * of 128 on MX-fp8 matrix instructions (v_mfma_scale_f32_16x16x128_f8f6f4: OCP e4m3 elements, one e8m0 power-of-two scale per 32
  * K elements; activations are quantised on the fly, weights once at bind time).  Reduced precision - the reference has no fp8 path;

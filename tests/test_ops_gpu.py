@@ -393,3 +393,22 @@ def test_loader_kernel_bitwise_full_size_conv(engine, T, H, W, C, O, kt, k):
             assert np.array_equal(got, ref), f"conv run {rep}: {np.abs(got - ref).max()}"
     finally:
         _force(engine, -1)
+
+
+@pytest.mark.parametrize("M,C", [(300, 64), (1000, 128), (4096, 192), (5000, 320), (77, 256)])
+def test_ff_fused_vs_reference_and_two_launch_path(engine, M, C):
+    """Fused GEGLU feed-forward (kernels/ff_fused.hip): c0 * (GEGLU(X W1^T + b1) W2^T + b2) + c1 * R1 against fp32 torch on fp16-rounded
+    operands, and against the two-GEMM-launch path it replaces (same roundings: fp16 intermediate, fp32 accumulation)."""
+    rng = np.random.default_rng(M + C)
+    I = 4 * C
+    X = h16(rng.standard_normal((M, C)))
+    W1, b1 = h16(rng.standard_normal((2 * I, C)) / np.sqrt(C)), h16(rng.standard_normal(2 * I) * 0.1)
+    W2, b2 = h16(rng.standard_normal((C, I)) / np.sqrt(I)), h16(rng.standard_normal(C) * 0.1)
+    R1 = h16(rng.standard_normal((M, C)))
+    got = engine.op_ff(X, W1, b1, W2, b2, R1=R1, c0=0.7, c1=1.3, fused=True)
+    two = engine.op_ff(X, W1, b1, W2, b2, R1=R1, c0=0.7, c1=1.3, fused=False)
+    h = t(X) @ t(W1).T + t(b1)
+    mid = (h[:, :I] * torch.nn.functional.gelu(h[:, I:])).half().float()
+    ref = (0.7 * (mid @ t(W2).T + t(b2)) + 1.3 * t(R1)).numpy()
+    assert_close(got, ref, 2e-3, f"fused GEGLU feed-forward {M}x{C}")
+    assert_close(got, two, 1.5e-3, f"fused vs two-launch feed-forward {M}x{C}")

@@ -18,7 +18,7 @@ EXPORTS = [
     "ug_unet_config_default", "ug_vae_config_default", "ug_clip_config_default",
     "ug_create", "ug_destroy", "ug_last_error", "ug_workspace_peak",
     "ug_load_tensor", "ug_bind_unet", "ug_bind_vae", "ug_bind_clip",
-    "ug_dc_set_inputs", "ug_dc_run", "ug_dc_run_windows", "ug_dc_get_outputs", "ug_dc_device_ptrs", "ug_dc_set_trace", "ug_set_vae_encode_fp32", "ug_set_fp8_linears", "ug_op_linear_mx8",
+    "ug_dc_set_inputs", "ug_dc_run", "ug_dc_run_windows", "ug_dc_get_outputs", "ug_dc_device_ptrs", "ug_dc_set_trace", "ug_set_vae_encode_fp32", "ug_set_fp8_linears", "ug_op_linear_mx8", "ug_set_ff_fused", "ug_op_ff",
     "ug_eval_depth", "ug_eval_normal", "ug_clip_embed", "ug_vae_encode", "ug_vae_decode", "ug_unet_forward", "ug_normals_from_depth",
     "ug_op_linear", "ug_op_conv", "ug_op_groupnorm", "ug_op_layernorm", "ug_op_flash_attn",
     "ug_op_temporal_attn", "ug_op_attention_generic", "ug_op_euler_step",
@@ -82,6 +82,8 @@ def load_library():
     lib.ug_dc_set_trace.argtypes = [vp, vp, ip]
     lib.ug_set_vae_encode_fp32.argtypes = [vp, ip]
     lib.ug_set_fp8_linears.argtypes = [vp, ip]
+    lib.ug_set_ff_fused.argtypes = [vp, ip]
+    lib.ug_op_ff.argtypes = [vp, vp, ip, ip, vp, vp, vp, vp, vp, C.c_float, C.c_float, ip, vp]
     lib.ug_op_linear_mx8.argtypes = [vp, vp, ip, ip, vp, ip, vp, ip, vp, vp, vp]
     lib.ug_dc_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.ug_eval_depth.argtypes = [vp, vp, vp, vp, C.c_long, C.c_float, vp]
@@ -275,6 +277,17 @@ class Engine:
     def set_vae_encode_fp32(self, on=True):
         """True (default) = the reference's float32 VAE encoder (force_upcast); False = fp16 storage like the decoder."""
         self._ck(self.lib.ug_set_vae_encode_fp32(self.ctx, int(bool(on))))
+
+    def set_ff_fused(self, on=True):
+        self._ck(self.lib.ug_set_ff_fused(self.ctx, int(bool(on))))
+
+    def op_ff(self, X, W1, b1, W2, b2, R1=None, c0=1.0, c1=1.0, fused=True):
+        X = _f32(X); M, Cc = X.shape
+        r = None if R1 is None else _f32(R1)
+        out = np.empty((M, Cc), np.float32)
+        self._ck(self.lib.ug_op_ff(self.ctx, _ptr(X), M, Cc, _ptr(_f32(W1)), _ptr(_f32(b1)), _ptr(_f32(W2)), _ptr(_f32(b2)), _ptr(r),
+                                   float(c0), float(c1), int(bool(fused)), _ptr(out)))
+        return out
 
     def set_fp8_linears(self, on=True):
         """MX-fp8 matrix instructions for the UNet transformers' linear layers (BASELINE configs[4]); reduced precision, default off."""

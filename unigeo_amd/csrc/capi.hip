@@ -121,6 +121,11 @@ int ug_dc_run(ug_ctx* x, int steps, int chunk, int with_normals) { UG_TRY(x, dc_
 int ug_dc_run_windows(ug_ctx* x, int steps, int chunk, int with_normals, int window, int overlap) {
   UG_TRY(x, dc_run(x->c, steps, chunk, with_normals, window, overlap));
 }
+int ug_set_ff_fused(ug_ctx* x, int on) {
+  if (!x) return -1;
+  x->c.ff_fused = on ? 1 : 0;
+  return 0;
+}
 int ug_set_fp8_linears(ug_ctx* x, int on) {
   if (!x) return -1;
   x->c.fp8_linears = on ? 1 : 0;
@@ -462,6 +467,39 @@ int ug_op_linear(ug_ctx* x, const float* A, int M, int K, const float* W, int N,
   });
 }
 
+int ug_op_ff(ug_ctx* x, const float* X, int M, int C, const float* W1, const float* b1, const float* W2, const float* b2, const float* R1,
+             float c0, float c1, int fused, float* out) {
+  UG_TRY(x, {
+    Ctx& c = x->c; Scope sc(c);
+    const int I = 4 * C;
+    // W1 / b1 in the engine's GEGLU row order: blocks of 16 rows = [8 value | 8 gate]
+    std::vector<float> w1((size_t)2 * I * C), bb1((size_t)2 * I);
+    for (int v = 0; v < 2 * I; ++v) {
+      const int blk = v / 16, wv = v % 16, src = wv < 8 ? blk * 8 + wv : I + blk * 8 + (wv - 8);
+      memcpy(&w1[(size_t)v * C], &W1[(size_t)src * C], sizeof(float) * C);
+      bb1[v] = b1[src];
+    }
+    f16* dX = up16(c, X, (long)M * C); f16* dW1 = up16(c, w1.data(), (long)2 * I * C); f16* db1 = up16(c, bb1.data(), 2 * I);
+    f16* dW2 = up16(c, W2, (long)C * I); f16* db2 = up16(c, b2, C); f16* dR = up16_opt(c, R1, (long)M * C);
+    f16* dO = c.ws.get<f16>((long)M * C);
+    if (fused) {
+      FFusedP p; memset(&p, 0, sizeof(p));
+      p.X = dX; p.W1 = dW1; p.b1 = db1; p.W2 = dW2; p.b2 = db2; p.R1 = dR; p.c0 = c0; p.c1 = c1; p.Out = dO; p.M = M; p.C = C; p.zero = c.zero;
+      launch_ff_fused(p, c.stream);
+    } else {
+      f16* mid = c.ws.get<f16>((long)M * I);
+      GemmP g1; memset(&g1, 0, sizeof(g1));
+      g1.A0 = dX; g1.C0 = C; g1.M = M; g1.N = 2 * I; g1.K = C; g1.W = dW1; g1.ldw = C; g1.bias = db1; g1.c0 = 1.f; g1.Out = mid; g1.ldo = I;
+      g1.flags = UG_F_GEGLU; g1.zero = c.zero; g1.nb_inner = 1;
+      launch_gemm(g1, 1, c.stream);
+      GemmP g2; memset(&g2, 0, sizeof(g2));
+      g2.A0 = mid; g2.C0 = I; g2.M = M; g2.N = C; g2.K = I; g2.W = dW2; g2.ldw = I; g2.bias = db2; g2.c0 = c0; g2.R1 = dR; g2.ldr1 = C; g2.c1 = c1;
+      g2.Out = dO; g2.ldo = C; g2.zero = c.zero; g2.nb_inner = 1; g2.splitk = 1;
+      launch_gemm(g2, 1, c.stream);
+    }
+    down16(c, dO, out, (long)M * C);
+  });
+}
 int ug_op_linear_mx8(ug_ctx* x, const float* A, int M, int K, const float* W, int N, const float* bias, int geglu, float* out,
                      unsigned char* a8_out, unsigned* sa_out) {
   UG_TRY(x, {

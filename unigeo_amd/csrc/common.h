@@ -77,6 +77,16 @@ void launch_gemm(const GemmP& p, int batch, hipStream_t s);
 void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out);   // heuristic used when cfg/splitk are 0
 void gemm_force(int cfg, int split);                                       // tuning aid: override the heuristic (-1 = off)
 
+// Fused GEGLU feed-forward (kernels/ff_fused.hip): Out = c0 * (GEGLU(X W1^T + b1) W2^T + b2) + c1 R1 + c2 R2, all [M, C] row-major (ld = C);
+// W1 [8C][C] / b1 [8C] in the bound GEGLU row order (blocks of 16 rows = [8 value | 8 gate]), W2 [C][4C], C in {64,...,320}
+struct FFusedP {
+  const f16* X; const f16* W1; const f16* b1; const f16* W2; const f16* b2;
+  const f16* R1; const f16* R2; float c0, c1, c2;
+  f16* Out; int M, C; const f16* zero;
+};
+bool ff_fused_supported(int C);
+void launch_ff_fused(const FFusedP& p, hipStream_t s);
+
 // ---------------------------------------------------------------------------------------
 // Normalisation (kernels/norm.hip)
 // ---------------------------------------------------------------------------------------

@@ -724,6 +724,19 @@ static f16* stres_forward(Ctx& c, const STRes& rb, const f16* x0, int C0, const 
 // MI355X: -3 % end to end (the smaller launches lose more than residency gains), so it is opt-in (UG_FF_CHUNK=1).
 static void ff_pair(Ctx& c, const f16* a, long M, const Lin& f1, const Lin& f2, f16* mid, f16* out, const Epi& e2) {
   const int C4 = f1.out / 2, C = f2.out;
+  // narrow blocks (level 0: C = 320): one fused kernel, the [M, 4C] intermediate never leaves the CU (kernels/ff_fused.hip)
+  if (c.ff_fused && !c.fp8_linears && ff_fused_supported(C) && f1.in == C && C4 == 4 * C && M >= 4096 && f1.b && !e2.act && !e2.flags &&
+      (!e2.R1 || !e2.ldr1 || e2.ldr1 == C) && (!e2.R2 || !e2.ldr2 || e2.ldr2 == C) && !e2.bias2) {
+    FFusedP p; memset(&p, 0, sizeof(p));
+    p.X = a; p.W1 = f1.w; p.b1 = f1.b; p.W2 = f2.w; p.b2 = f2.b; p.R1 = e2.R1; p.R2 = e2.R2; p.c0 = e2.c0; p.c1 = e2.c1; p.c2 = e2.c2;
+    p.Out = out; p.M = (int)M; p.C = C; p.zero = c.zero;
+    char nm[64];
+    if (c.prof_on && c.prof_shapes) snprintf(nm, sizeof(nm), "gemm_ff_fused:%ldx%d", M, C); else snprintf(nm, sizeof(nm), "gemm_ff_fused");
+    ProfScope ps(c, nm, 2.0 * M * (double)(2 * C4) * C + 2.0 * M * (double)C * C4,
+                 2.0 * ((double)M * C * (2 + (e2.R1 ? 1 : 0) + (e2.R2 ? 1 : 0)) + 3.0 * (double)C4 * C));
+    launch_ff_fused(p, c.stream);
+    return;
+  }
   const long bytes = M * C4 * 2;
   int nchunk = 1;
   if (bytes > (96L << 20) && getenv("UG_FF_CHUNK")) nchunk = (int)((bytes + (48L << 20) - 1) / (48L << 20));

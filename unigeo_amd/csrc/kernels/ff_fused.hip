@@ -1,0 +1,277 @@
+// Fused GEGLU feed-forward for the narrow (level-0, C = 320) transformer blocks on gfx950:
+//
+//   Out[M, C] = c0 * ( GEGLU( X[M,C] . W1^T + b1 )[M, 4C] . W2^T + b2 ) + c1 * R1 + c2 * R2
+//
+// As two GEMM launches this pair is the worst-behaved part of the clip (profiles/r02_per_shape_hip_events_25step.txt): the
+// projection (K = 320: five K steps under a GEGLU epilogue) runs at 640 TFLOP/s and writes a 197 MB intermediate that the
+// down-projection (N = 320) then re-reads once per 128-column tile from the Infinity Cache / HBM at 490 TFLOP/s.  Here the
+// [M, 4C] intermediate never leaves the CU:
+//
+// * workgroup = 8 wave64 (4 along M x 2 along N), BM = 128 token rows; the X tile [128 x C] is staged ONCE into LDS
+//   (C/64 K tiles of [128 x 64], 16-byte chunks XOR-swizzled on the source address like the GEMM's tiles);
+// * the inner dimension is walked in chunks of 64 GEGLU outputs (= 128 rows of W1, already row-interleaved [8 value | 8 gate]
+//   at bind time).  Phase A: acc1[128 x 128] = X . W1c^T over C/64 K steps -> + b1 -> GEGLU in registers -> fp16 -> G tile
+//   [128 x 64] in LDS.  Phase B: acc2[128 x C] += G . W2c^T, W2c = the 64 matching columns of W2, taken in pieces of 128 output
+//   columns (+ one of 64) so that EVERY streamed operand packet is a [<=128 x 64] fp16 tile = 16 KiB;
+// * all weight packets flow through one 3-slot LDS ring by direct-to-LDS loads issued two packets ahead, one barrier per packet
+//   (same protocol as gemm_kernel: raw s_barrier, counted vmcnt, LDS-DMA stays in flight across barriers);
+// * swapped MFMA operands + permuted weight rows give every lane 16 (8 in the last piece) contiguous output columns: bias,
+//   GEGLU, residuals and stores are 16-byte vectors.
+// LDS: X 16 KiB * C/64 + ring 48 KiB + G 16 KiB = 144 KiB at C = 320; registers: acc2 80 + acc1 32 per lane.
+#include "../common.h"
+#include <algorithm>
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// same packed-fp32 GEGLU as the GEMM epilogue (kernels/gemm.hip): h * g * Phi(g), erfc by Abramowitz-Stegun 7.1.26
+__device__ __forceinline__ f32x2 ff_geglu2(f32x2 h, f32x2 g) {
+  const f32x2 ag = {__builtin_fabsf(g.x), __builtin_fabsf(g.y)};
+  const f32x2 u = ag * 0.23164189f + 1.0f;
+  const f32x2 t = {__builtin_amdgcn_rcpf(u.x), __builtin_amdgcn_rcpf(u.y)};
+  f32x2 y = t * 0.5307027145f - 0.7265760135f;
+  y = y * t + 0.7107068705f;
+  y = y * t - 0.142248368f;
+  y = y * t + 0.127414796f;
+  y = y * t;
+  const f32x2 w = (g * g) * -0.72134752044f;
+  const f32x2 e = {__builtin_amdgcn_exp2f(w.x), __builtin_amdgcn_exp2f(w.y)};
+  const f32x2 q = 0.5f - y * e;
+  const f32x2 phi = {0.5f + __builtin_copysignf(q.x, g.x), 0.5f + __builtin_copysignf(q.y, g.y)};
+  return h * g * phi;
+}
+
+__device__ __forceinline__ int ffswz(int row) { return (row >> 1) & 7; }   // 128-byte rows, 16-byte chunks
+
+template <int KT>   // KT = C / 64 K tiles of the X operand (C = 64 * KT <= 320)
+__global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
+  constexpr int C = KT * 64;
+  constexpr int NP = (C + 127) / 128;          // phase-B pieces: NPF full ones of 128 output columns + (C % 128 == 64) one of 64
+  constexpr int NPF = C / 128;
+  constexpr bool TAIL = (C % 128) != 0;
+  constexpr int STEPS = KT + NP;               // packets per chunk
+  constexpr int TILE = 128 * 64;               // halves per [128 x 64] tile
+  extern __shared__ __attribute__((aligned(16))) f16 smem[];
+  f16* Xs = smem;                              // [KT][128][64]
+  f16* ring = smem + KT * TILE;                // [3][128][64]
+  f16* Gs = ring + 3 * TILE;                   // [128][64]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int sw = ffswz(l15);
+  const int pc = lane & 7, lrow = lane >> 3;
+  const int I = 4 * C;                         // inner width (GEGLU outputs); W1 has 2*I rows
+  const int nchunk = I / 64;
+  const int ntiles = (p.M + 127) / 128;
+
+  // ---- weight packet q of chunk j -> ring slot `slot`.  Every wave issues 2 (full packets) or 1 (64-row tail piece) load.
+  auto issue_packet = [&](int j, int s, int slot) {
+    f16* dst = ring + slot * TILE;
+    if (s < KT) {   // W1 rows [j*128, +128), K tile s; LDS row lr holds W1 row j*128 + perm(lr) (wave tile 64, 16 columns per lane)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int lr = (wave * 2 + u) * 8 + lrow;
+        const int part = lr >> 6, rem = lr & 63, jj = rem >> 4, i = rem & 15;
+        const int n = j * 128 + part * 64 + (i >> 2) * 16 + jj * 4 + (i & 3);
+        const f16* src = p.W1 + (long)n * C + s * 64 + ((pc ^ ffswz(lr)) * 8);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + (wave * 2 + u) * 8 * 64), 16, 0, 0);
+      }
+    } else if (s - KT < NPF) {   // W2 rows [pp*128, +128) (output columns), K columns [j*64, +64)
+      const int pp = s - KT;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int lr = (wave * 2 + u) * 8 + lrow;
+        const int part = lr >> 6, rem = lr & 63, jj = rem >> 4, i = rem & 15;
+        const int n = pp * 128 + part * 64 + (i >> 2) * 16 + jj * 4 + (i & 3);
+        const f16* src = p.W2 + (long)n * I + j * 64 + ((pc ^ ffswz(lr)) * 8);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + (wave * 2 + u) * 8 * 64), 16, 0, 0);
+      }
+    } else {   // tail piece: 64 output columns, wave tile 32 (8 columns per lane)
+      const int lr = wave * 8 + lrow;
+      const int part = lr >> 5, rem = lr & 31, jj = rem >> 4, i = rem & 15;
+      const int n = NPF * 128 + part * 32 + (i >> 2) * 8 + jj * 4 + (i & 3);
+      const f16* src = p.W2 + (long)n * I + j * 64 + ((pc ^ ffswz(lr)) * 8);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + wave * 8 * 64), 16, 0, 0);
+    }
+  };
+  // loads per wave of packet s (compile-time when s is)
+  auto nload = [](int s) { return (TAIL && s == STEPS - 1) ? 1 : 2; };
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m0 = tile * 128;
+    // ---- X tile: KT x 16 wave-instructions of 1 KiB, spread over the 8 waves
+    for (int t = wave; t < KT * 16; t += 8) {
+      const int kt = t >> 4, r = t & 15;
+      const int lr = r * 8 + lrow, m = m0 + lr;
+      const f16* src = (m < p.M) ? p.X + (long)m * C + kt * 64 + ((pc ^ ffswz(lr)) * 8) : p.zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + kt * TILE + r * 8 * 64), 16, 0, 0);
+    }
+    issue_packet(0, 0, 0);
+    issue_packet(0, 1, 1);
+
+    f32x4 acc1[2][4], acc2[NP][2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jn = 0; jn < 4; ++jn) {
+        acc1[i][jn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) acc2[pp][i][jn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+
+    int slot = 0;                       // ring slot of the packet being consumed
+    bool first = true;                  // the X tile's loads are still in flight before the very first packet
+    for (int j = 0; j < nchunk; ++j) {
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s) {
+        // packet (j, s) must have landed; the next packet (issued one step ago) may stay in flight
+        const bool last = (j == nchunk - 1) && (s == STEPS - 1);
+        if (first || last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (nload((s + 1) % STEPS) == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (first) {   // steady state below assumes exactly one younger packet in flight: re-establish it
+          first = false;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's G-tile writes (end of phase A) are done before the barrier publishes them
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        {   // fetch the packet two ahead into the slot everybody finished reading in the previous step
+          int s2 = s + 2, j2 = j;
+          if (s2 >= STEPS) { s2 -= STEPS; ++j2; }
+          int slot2 = slot + 2; if (slot2 >= 3) slot2 -= 3;
+          if (j2 < nchunk) issue_packet(j2, s2, slot2);
+        }
+        const f16* Wt = ring + slot * TILE;
+        if (++slot == 3) slot = 0;
+        if (s < KT) {
+          // ---- phase A, K tile s: acc1 += X[:, s] . W1c[:, s]^T   (wave: 32 rows x 64 W1 rows)
+          const f16* Ab = Xs + s * TILE + (wm * 32 + l15) * 64;
+          const f16* Bb = Wt + (wn * 64 + l15) * 64;
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const int ch = ((kk * 4 + g) ^ sw) * 8;
+            f16x8 bf[4], af[2];
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) bf[jn] = *(const f16x8*)(Bb + jn * 16 * 64 + ch);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *(const f16x8*)(Ab + i * 16 * 64 + ch);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int jn = 0; jn < 4; ++jn) acc1[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[jn], af[i], acc1[i][jn], 0, 0, 0);
+          }
+          if (s == KT - 1) {
+            // ---- GEGLU: lane holds W1 rows j*128 + wn*64 + g*16 + [0,16) = [8 value | 8 gate] of inner columns j*64 + wn*32 + g*8 + [0,8)
+            const f16x8 b0 = *(const f16x8*)(p.b1 + j * 128 + wn * 64 + g * 16), b1v = *(const f16x8*)(p.b1 + j * 128 + wn * 64 + g * 16 + 8);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              float v[16];
+#pragma unroll
+              for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[jn * 4 + r] = acc1[i][jn][r] + (float)(jn < 2 ? b0[jn * 4 + r] : b1v[(jn - 2) * 4 + r]);
+              f16x8 o;
+#pragma unroll
+              for (int e = 0; e < 8; e += 2) {
+                const f32x2 r2 = ff_geglu2((f32x2){v[e], v[e + 1]}, (f32x2){v[8 + e], v[9 + e]});
+                o[e] = (f16)r2.x; o[e + 1] = (f16)r2.y;
+              }
+              const int row = wm * 32 + i * 16 + l15;
+              *(f16x8*)(Gs + row * 64 + (((wn * 4 + g) ^ ffswz(row)) * 8)) = o;
+#pragma unroll
+              for (int jn = 0; jn < 4; ++jn) acc1[i][jn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+          }
+        } else {
+          // ---- phase B, piece pp: acc2[pp] += G . W2c[piece]^T
+          const int pp = s - KT;
+          const f16* Ab = Gs + (wm * 32 + l15) * 64;
+          const bool tailp = TAIL && pp == NP - 1;
+          const f16* Bb = Wt + ((tailp ? wn * 32 : wn * 64) + l15) * 64;
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const int ch = ((kk * 4 + g) ^ sw) * 8;
+            f16x8 bf[4], af[2];
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn)
+              if (!tailp || jn < 2) bf[jn] = *(const f16x8*)(Bb + jn * 16 * 64 + ch);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *(const f16x8*)(Ab + i * 16 * 64 + ch);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int jn = 0; jn < 4; ++jn)
+                if (!tailp || jn < 2) acc2[pp][i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[jn], af[i], acc2[pp][i][jn], 0, 0, 0);
+          }
+        }
+      }
+    }
+
+    // ---- tile epilogue: out = c0 * (acc2 + b2) + c1 * R1 + c2 * R2; lane: rows wm*32 + i*16 + l15, 16 (tail: 8) contiguous columns
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) {
+      const bool tailp = TAIL && pp == NP - 1;
+      const int wid = tailp ? 8 : 16;
+      const int n0 = pp * 128 + (tailp ? wn * 32 + g * 8 : wn * 64 + g * 16);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 32 + i * 16 + l15;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int e0 = 0; e0 < 16; e0 += 8) {
+          if (e0 >= wid) continue;
+          const f16x8 b = p.b2 ? *(const f16x8*)(p.b2 + n0 + e0) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+          float o[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) o[q] = p.c0 * (acc2[pp][i][(e0 + q) >> 2][(e0 + q) & 3] + (float)b[q]);
+          if (p.R1) {
+            const f16x8 r = *(const f16x8*)(p.R1 + (long)m * C + n0 + e0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] += p.c1 * (float)r[q];
+          }
+          if (p.R2) {
+            const f16x8 r = *(const f16x8*)(p.R2 + (long)m * C + n0 + e0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] += p.c2 * (float)r[q];
+          }
+          f16x8 h;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) h[q] = (f16)o[q];
+          *(f16x8*)(p.Out + (long)m * C + n0 + e0) = h;
+        }
+      }
+    }
+    // the next tile's X loads overwrite Xs / the ring: everybody must be past this tile's LDS reads, and the epilogue's
+    // loads / stores must not be counted against the next tile's packets
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
+template <int KT>
+static void launch_ff_t(const FFusedP& p, hipStream_t s) {
+  const size_t lds = (size_t)(KT + 3 + 1) * 128 * 64 * sizeof(f16);
+  static bool attr = false;
+  if (!attr) { UG_CHECK(hipFuncSetAttribute((const void*)ff_fused_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  const int ntiles = (p.M + 127) / 128;
+  const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / lds)));
+  const int grid = std::min(ntiles, per_cu * 256);
+  hipLaunchKernelGGL(ff_fused_kernel<KT>, dim3(grid), dim3(512), lds, s, p);
+}
+
+bool ff_fused_supported(int C) { return C == 64 || C == 128 || C == 192 || C == 256 || C == 320; }
+
+void launch_ff_fused(const FFusedP& p, hipStream_t s) {
+  UG_REQUIRE(ff_fused_supported(p.C) && p.M > 0 && p.zero, "ff_fused: C must be a multiple of 64 up to 320");
+  switch (p.C / 64) {
+    case 1: launch_ff_t<1>(p, s); break;
+    case 2: launch_ff_t<2>(p, s); break;
+    case 3: launch_ff_t<3>(p, s); break;
+    case 4: launch_ff_t<4>(p, s); break;
+    default: launch_ff_t<5>(p, s); break;
+  }
+  UG_CHECK(hipGetLastError());
+}
