@@ -101,6 +101,7 @@ int ug_set_vae_encode_fp32(ug_ctx* ctx, int on);
  * FeedForward module inside the un-vendored UNet): ug_set_ff_fused(0) falls back to two GEMM launches; ug_op_ff evaluates
  * c0 * (GEGLU(X W1^T + b1) W2^T + b2) + c1 * R1 on [M, C] with either implementation (W1 [8C][C], b1 [8C], W2 [C][4C] in diffusers order). */
 int ug_set_ff_fused(ug_ctx* ctx, int on);
+int ug_bench_ff(ug_ctx* ctx, int M, int C, int fused, int iters, float* us_out);
 int ug_op_ff(ug_ctx* ctx, const float* X, int M, int C, const float* W1, const float* b1, const float* W2, const float* b2, const float* R1,
              float c0, float c1, int fused, float* out);
 /* BASELINE configs[4] (north_star: "fp8 MFMA ... (CDNA4 fp8)"): on = 1 runs the UNet transformers' linear layers whose K is a multiple

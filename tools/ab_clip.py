@@ -1,0 +1,25 @@
+#!/usr/bin/env python
+"""In-process A/B of engine switches on the full-size clip (25 x 384 x 512, 25 steps): box-to-box spread is +-4 %, so variants are
+only ever compared inside one process.  usage: ab_clip.py ff_fused|fp8|vae32 [repeats]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from unigeo_amd.pipeline import DepthCrafterPipelineHIP, make_noise
+from unigeo_amd.synthetic import synthetic_clip
+from unigeo_amd.model.depthcrafter import DepthCrafter
+what = sys.argv[1] if len(sys.argv) > 1 else "ff_fused"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+T, H, W = 25, 384, 512
+pipe = DepthCrafterPipelineHIP.from_random(seed=42, workspace_bytes=40 << 30)
+eng = pipe.engine
+clip = synthetic_clip(T, H, W)
+nl, na = make_noise(T, H, W, 0)
+eng.set_inputs(DepthCrafter.prepare_input(None, clip), nl, na, np.stack(clip["intrinsics"], 0))
+setter = {"ff_fused": eng.set_ff_fused, "fp8": eng.set_fp8_linears, "vae32": eng.set_vae_encode_fp32}[what]
+eng.run(25, 8)
+for rnd in range(reps):
+    for on in (False, True):
+        setter(on)
+        eng.run(25, 8)
+        t0 = time.perf_counter(); eng.run(25, 8); eng.run(25, 8); dt = (time.perf_counter() - t0) / 2
+        print(f"round {rnd} {what}={int(on)}: {dt * 1e3:8.1f} ms/clip  {T / dt:6.2f} frames/s", flush=True)

@@ -15,6 +15,10 @@ clip = synthetic_clip(T, H, W)
 frames = DepthCrafter.prepare_input(None, clip)
 nl, na = make_noise(T, H, W, 0)
 eng.set_inputs(frames, nl, na, np.stack(clip["intrinsics"], 0))
+if os.environ.get("UG_FP8"):
+    eng.set_fp8_linears(True)           # BASELINE configs[4] option: MX-fp8 linear layers
+if os.environ.get("UG_NO_FF_FUSED"):
+    eng.set_ff_fused(False)
 eng.run(1, 8)
 eng.profile_begin(shapes=True)
 eng.run(steps, 8)

@@ -12,13 +12,13 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libunigeo_hip.so")
+LIB_PATH = os.environ.get("UG_LIB_PATH") or os.path.join(_HERE, "csrc", "libunigeo_hip.so")   # UG_LIB_PATH: A/B a second build of the SAME library (tools/ab)
 
 EXPORTS = [
     "ug_unet_config_default", "ug_vae_config_default", "ug_clip_config_default",
     "ug_create", "ug_destroy", "ug_last_error", "ug_workspace_peak",
     "ug_load_tensor", "ug_bind_unet", "ug_bind_vae", "ug_bind_clip",
-    "ug_dc_set_inputs", "ug_dc_run", "ug_dc_run_windows", "ug_dc_get_outputs", "ug_dc_device_ptrs", "ug_dc_set_trace", "ug_set_vae_encode_fp32", "ug_set_fp8_linears", "ug_op_linear_mx8", "ug_set_ff_fused", "ug_op_ff",
+    "ug_dc_set_inputs", "ug_dc_run", "ug_dc_run_windows", "ug_dc_get_outputs", "ug_dc_device_ptrs", "ug_dc_set_trace", "ug_set_vae_encode_fp32", "ug_set_fp8_linears", "ug_op_linear_mx8", "ug_set_ff_fused", "ug_op_ff", "ug_bench_ff",
     "ug_eval_depth", "ug_eval_normal", "ug_clip_embed", "ug_vae_encode", "ug_vae_decode", "ug_unet_forward", "ug_normals_from_depth",
     "ug_op_linear", "ug_op_conv", "ug_op_groupnorm", "ug_op_layernorm", "ug_op_flash_attn",
     "ug_op_temporal_attn", "ug_op_attention_generic", "ug_op_euler_step",
@@ -81,10 +81,15 @@ def load_library():
     lib.ug_dc_get_outputs.argtypes = [vp, vp, vp, vp]
     lib.ug_dc_set_trace.argtypes = [vp, vp, ip]
     lib.ug_set_vae_encode_fp32.argtypes = [vp, ip]
-    lib.ug_set_fp8_linears.argtypes = [vp, ip]
-    lib.ug_set_ff_fused.argtypes = [vp, ip]
-    lib.ug_op_ff.argtypes = [vp, vp, ip, ip, vp, vp, vp, vp, vp, C.c_float, C.c_float, ip, vp]
-    lib.ug_op_linear_mx8.argtypes = [vp, vp, ip, ip, vp, ip, vp, ip, vp, vp, vp]
+    try:
+        lib.ug_set_fp8_linears.argtypes = [vp, ip]
+        lib.ug_set_ff_fused.argtypes = [vp, ip]
+        lib.ug_bench_ff.argtypes = [vp, ip, ip, ip, ip, vp]
+        lib.ug_op_ff.argtypes = [vp, vp, ip, ip, vp, vp, vp, vp, vp, C.c_float, C.c_float, ip, vp]
+        lib.ug_op_linear_mx8.argtypes = [vp, vp, ip, ip, vp, ip, vp, ip, vp, vp, vp]
+    except AttributeError:
+        if not os.environ.get("UG_LIB_PATH"):      # only an explicitly selected OLDER build (tools/ab A/B runs) may lack these
+            raise
     lib.ug_dc_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.ug_eval_depth.argtypes = [vp, vp, vp, vp, C.c_long, C.c_float, vp]
     lib.ug_eval_normal.argtypes = [vp, vp, vp, vp, C.c_long, vp]
@@ -277,6 +282,11 @@ class Engine:
     def set_vae_encode_fp32(self, on=True):
         """True (default) = the reference's float32 VAE encoder (force_upcast); False = fp16 storage like the decoder."""
         self._ck(self.lib.ug_set_vae_encode_fp32(self.ctx, int(bool(on))))
+
+    def bench_ff(self, M, C, fused=True, iters=20):
+        out = np.zeros(1, np.float32)
+        self._ck(self.lib.ug_bench_ff(self.ctx, int(M), int(C), int(bool(fused)), int(iters), _ptr(out)))
+        return float(out[0])
 
     def set_ff_fused(self, on=True):
         self._ck(self.lib.ug_set_ff_fused(self.ctx, int(bool(on))))

@@ -500,6 +500,43 @@ int ug_op_ff(ug_ctx* x, const float* X, int M, int C, const float* W1, const flo
     down16(c, dO, out, (long)M * C);
   });
 }
+int ug_bench_ff(ug_ctx* x, int M, int C, int fused, int iters, float* us_out) {
+  UG_TRY(x, {
+    Ctx& c = x->c; Scope sc(c);
+    const int I = 4 * C;
+    f16* dX = c.ws.get<f16>((long)M * C); f16* dW1 = c.ws.get<f16>((long)2 * I * C); f16* db1 = c.ws.get<f16>(2 * I);
+    f16* dW2 = c.ws.get<f16>((long)C * I); f16* db2 = c.ws.get<f16>(C); f16* dR = c.ws.get<f16>((long)M * C);
+    f16* dO = c.ws.get<f16>((long)M * C); f16* mid = c.ws.get<f16>((long)M * I);
+    launch_fill_random(dX, (long)M * C, 1, c.stream); launch_fill_random(dW1, (long)2 * I * C, 2, c.stream); launch_fill_random(db1, 2 * I, 3, c.stream);
+    launch_fill_random(dW2, (long)C * I, 4, c.stream); launch_fill_random(db2, C, 5, c.stream); launch_fill_random(dR, (long)M * C, 6, c.stream);
+    launch_scale_f16(dW1, dW1, 0.05f, (long)2 * I * C, c.stream); launch_scale_f16(dW2, dW2, 0.03f, (long)C * I, c.stream);
+    auto run = [&]() {
+      if (fused) {
+        FFusedP p; memset(&p, 0, sizeof(p));
+        p.X = dX; p.W1 = dW1; p.b1 = db1; p.W2 = dW2; p.b2 = db2; p.R1 = dR; p.c0 = 1.f; p.c1 = 1.f; p.Out = dO; p.M = M; p.C = C; p.zero = c.zero;
+        launch_ff_fused(p, c.stream);
+      } else {
+        GemmP g1; memset(&g1, 0, sizeof(g1));
+        g1.A0 = dX; g1.C0 = C; g1.M = M; g1.N = 2 * I; g1.K = C; g1.W = dW1; g1.ldw = C; g1.bias = db1; g1.c0 = 1.f; g1.Out = mid; g1.ldo = I;
+        g1.flags = UG_F_GEGLU; g1.zero = c.zero; g1.nb_inner = 1;
+        launch_gemm(g1, 1, c.stream);
+        GemmP g2; memset(&g2, 0, sizeof(g2));
+        g2.A0 = mid; g2.C0 = I; g2.M = M; g2.N = C; g2.K = I; g2.W = dW2; g2.ldw = I; g2.bias = db2; g2.c0 = 1.f; g2.R1 = dR; g2.ldr1 = C; g2.c1 = 1.f;
+        g2.Out = dO; g2.ldo = C; g2.zero = c.zero; g2.nb_inner = 1; g2.splitk = 1;
+        launch_gemm(g2, 1, c.stream);
+      }
+    };
+    run(); run();
+    hipEvent_t e0, e1; UG_CHECK(hipEventCreate(&e0)); UG_CHECK(hipEventCreate(&e1));
+    UG_CHECK(hipEventRecord(e0, c.stream));
+    for (int i = 0; i < iters; ++i) run();
+    UG_CHECK(hipEventRecord(e1, c.stream));
+    UG_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f; UG_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *us_out = ms * 1000.f / iters;
+  });
+}
 int ug_op_linear_mx8(ug_ctx* x, const float* A, int M, int K, const float* W, int N, const float* bias, int geglu, float* out,
                      unsigned char* a8_out, unsigned* sa_out) {
   UG_TRY(x, {

@@ -108,8 +108,11 @@ static void linear(Ctx& c, const f16* A, long M, const Lin& l, f16* out, const E
     unsigned char* a8 = (unsigned char*)c.ws.alloc((size_t)M * K);
     const long ld_sa = pad256(M);
     unsigned* sa = (unsigned*)c.ws.alloc((size_t)(K / 128) * ld_sa * 4);
+    char nmq[96], nmg[96];
+    if (c.prof_on && c.prof_shapes) { snprintf(nmq, sizeof(nmq), "quant_mx8:%ldx%d", M, K); snprintf(nmg, sizeof(nmg), "gemm_linear_mx8:%ldx%dx%d", M, l.out, K); }
+    else { snprintf(nmq, sizeof(nmq), "quant_mx8"); snprintf(nmg, sizeof(nmg), "gemm_linear_mx8"); }
     {
-      ProfScope ps(c, "quant_mx8", 0, (double)M * K * 3.0);
+      ProfScope ps(c, nmq, 0, (double)M * K * 3.0);
       launch_quant_mx8(A, lda ? lda : K, M, K, a8, sa, ld_sa, c.stream);
     }
     p.A0 = (const f16*)a8; p.C0 = K; p.M = (int)M; p.N = l.out; p.K = K;
@@ -122,7 +125,7 @@ static void linear(Ctx& c, const f16* A, long M, const Lin& l, f16* out, const E
     if (p.R2 && !p.ldr2) p.ldr2 = nout;
     p.sa = sa; p.ld_sa = ld_sa; p.sw = l.sw8; p.ld_sw = l.ld_sw8; p.zero = c.zero; p.nb_inner = 1;
     {
-      ProfScope ps(c, "gemm_linear_mx8", 2.0 * M * (double)l.out * K, (double)M * K + (double)l.out * K + 2.0 * M * nout);
+      ProfScope ps(c, nmg, 2.0 * M * (double)l.out * K, (double)M * K + (double)l.out * K + 2.0 * M * nout);
       launch_gemm_mx8(p, c.stream);
     }
     c.ws.release(mk);
@@ -725,7 +728,7 @@ static f16* stres_forward(Ctx& c, const STRes& rb, const f16* x0, int C0, const 
 static void ff_pair(Ctx& c, const f16* a, long M, const Lin& f1, const Lin& f2, f16* mid, f16* out, const Epi& e2) {
   const int C4 = f1.out / 2, C = f2.out;
   // narrow blocks (level 0: C = 320): one fused kernel, the [M, 4C] intermediate never leaves the CU (kernels/ff_fused.hip)
-  if (c.ff_fused && !c.fp8_linears && ff_fused_supported(C) && f1.in == C && C4 == 4 * C && M >= 4096 && f1.b && !e2.act && !e2.flags &&
+  if (c.ff_fused && !c.fp8_linears && ff_fused_supported(C) && f1.in == C && C4 == 4 * C && M >= 32768 && f1.b && !e2.act && !e2.flags &&
       (!e2.R1 || !e2.ldr1 || e2.ldr1 == C) && (!e2.R2 || !e2.ldr2 || e2.ldr2 == C) && !e2.bias2) {
     FFusedP p; memset(&p, 0, sizeof(p));
     p.X = a; p.W1 = f1.w; p.b1 = f1.b; p.W2 = f2.w; p.b2 = f2.b; p.R1 = e2.R1; p.R2 = e2.R2; p.c0 = e2.c0; p.c1 = e2.c1; p.c2 = e2.c2;

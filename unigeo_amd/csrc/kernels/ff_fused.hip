@@ -67,34 +67,42 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
   const int nchunk = I / 64;
   const int ntiles = (p.M + 127) / 128;
 
-  // ---- weight packet q of chunk j -> ring slot `slot`.  Every wave issues 2 (full packets) or 1 (64-row tail piece) load.
+  // ---- buffer-addressed direct-to-LDS loads: the per-lane byte offset of every load is fixed for the whole kernel (row permutation,
+  // swizzled 16-byte chunk), the packet position is a scalar offset - no address arithmetic on the issue path
+  constexpr unsigned SENT = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rW1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.W1, 0, (int)SENT, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.W2, 0, (int)SENT, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (int)((long)p.M * C * 2), 0x00020000);   // rows >= M read zeros
+  unsigned vo1[2], vo2[2], vot, vox;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {   // LDS row lr holds weight row perm(lr): wave tile 64, 16 contiguous columns per lane
+    const int lr = (wave * 2 + u) * 8 + lrow;
+    const int part = lr >> 6, rem = lr & 63, jj = rem >> 4, i = rem & 15;
+    const int n = part * 64 + (i >> 2) * 16 + jj * 4 + (i & 3);
+    vo1[u] = (unsigned)((n * C + (pc ^ ffswz(lr)) * 8) * 2);
+    vo2[u] = (unsigned)((n * I + (pc ^ ffswz(lr)) * 8) * 2);
+  }
+  {   // tail piece: 64 output columns, wave tile 32 (8 columns per lane)
+    const int lr = wave * 8 + lrow;
+    const int part = lr >> 5, rem = lr & 31, jj = rem >> 4, i = rem & 15;
+    const int n = NPF * 128 + part * 32 + (i >> 2) * 8 + jj * 4 + (i & 3);
+    vot = (unsigned)((n * I + (pc ^ ffswz(lr)) * 8) * 2);
+  }
+  vox = (unsigned)((lrow * C + 0) * 2);   // X rows: + (r*8) rows and the swizzled chunk are added per load (the swizzle depends on r)
   auto issue_packet = [&](int j, int s, int slot) {
     f16* dst = ring + slot * TILE;
-    if (s < KT) {   // W1 rows [j*128, +128), K tile s; LDS row lr holds W1 row j*128 + perm(lr) (wave tile 64, 16 columns per lane)
+    if (s < KT) {   // W1 rows [j*128, +128), K tile s
+      const int so = (j * 128 * C + s * 64) * 2;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int lr = (wave * 2 + u) * 8 + lrow;
-        const int part = lr >> 6, rem = lr & 63, jj = rem >> 4, i = rem & 15;
-        const int n = j * 128 + part * 64 + (i >> 2) * 16 + jj * 4 + (i & 3);
-        const f16* src = p.W1 + (long)n * C + s * 64 + ((pc ^ ffswz(lr)) * 8);
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + (wave * 2 + u) * 8 * 64), 16, 0, 0);
-      }
+      for (int u = 0; u < 2; ++u)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW1, (lptr_t)(dst + (wave * 2 + u) * 8 * 64), 16, (int)vo1[u], so, 0, 0);
     } else if (s - KT < NPF) {   // W2 rows [pp*128, +128) (output columns), K columns [j*64, +64)
-      const int pp = s - KT;
+      const int so = ((s - KT) * 128 * I + j * 64) * 2;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int lr = (wave * 2 + u) * 8 + lrow;
-        const int part = lr >> 6, rem = lr & 63, jj = rem >> 4, i = rem & 15;
-        const int n = pp * 128 + part * 64 + (i >> 2) * 16 + jj * 4 + (i & 3);
-        const f16* src = p.W2 + (long)n * I + j * 64 + ((pc ^ ffswz(lr)) * 8);
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + (wave * 2 + u) * 8 * 64), 16, 0, 0);
-      }
-    } else {   // tail piece: 64 output columns, wave tile 32 (8 columns per lane)
-      const int lr = wave * 8 + lrow;
-      const int part = lr >> 5, rem = lr & 31, jj = rem >> 4, i = rem & 15;
-      const int n = NPF * 128 + part * 32 + (i >> 2) * 8 + jj * 4 + (i & 3);
-      const f16* src = p.W2 + (long)n * I + j * 64 + ((pc ^ ffswz(lr)) * 8);
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + wave * 8 * 64), 16, 0, 0);
+      for (int u = 0; u < 2; ++u)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW2, (lptr_t)(dst + (wave * 2 + u) * 8 * 64), 16, (int)vo2[u], so, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW2, (lptr_t)(dst + wave * 8 * 64), 16, (int)vot, j * 64 * 2, 0, 0);
     }
   };
   // loads per wave of packet s (compile-time when s is)
@@ -105,9 +113,9 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
     // ---- X tile: KT x 16 wave-instructions of 1 KiB, spread over the 8 waves
     for (int t = wave; t < KT * 16; t += 8) {
       const int kt = t >> 4, r = t & 15;
-      const int lr = r * 8 + lrow, m = m0 + lr;
-      const f16* src = (m < p.M) ? p.X + (long)m * C + kt * 64 + ((pc ^ ffswz(lr)) * 8) : p.zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + kt * TILE + r * 8 * 64), 16, 0, 0);
+      const int lr = r * 8 + lrow;
+      const unsigned vo = vox + (unsigned)((r * 8 * C + (pc ^ ffswz(lr)) * 8) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lptr_t)(Xs + kt * TILE + r * 8 * 64), 16, (int)vo, (m0 * C + kt * 64) * 2, 0, 0);
     }
     issue_packet(0, 0, 0);
     issue_packet(0, 1, 1);
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
         if (first) {   // steady state below assumes exactly one younger packet in flight: re-establish it
           first = false;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's G-tile writes (end of phase A) are done before the barrier publishes them
+        if (s == KT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's G-tile writes (end of phase A) are done before the barrier publishes them
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         {   // fetch the packet two ahead into the slot everybody finished reading in the previous step

@@ -1263,7 +1263,10 @@ void launch_gemm_mx8(const GemmP& p0, hipStream_t s) {
   p.splitk = 1; p.cfg_p1 = 0;
   if (g_knobs & 2) p.flags |= UG_F_NOXCD;
   const int force = g_force_cfg;
-  const int pick = force >= 100 ? force - 100 : (p.M <= 2048 ? 2 : (p.N >= 512 || p.N % 256 == 0) ? 0 : 1);
+  // largest tile that still gives the 256 CUs ~one workgroup each (profiles/r02_mx8_per_shape.txt: 4800x1280x5120 on 256x256 tiles = 95
+  // workgroups ran below the fp16 kernel)
+  const long t256 = (long)cdiv(p.M, 256) * cdiv(p.N, 256), t128n = (long)cdiv(p.M, 256) * cdiv(p.N, 128);
+  const int pick = force >= 100 ? force - 100 : (t256 >= 200 ? 0 : t128n >= 200 ? 1 : 2);
   switch (pick) {
     case 0: launch_mx<256, 256, 2, 2, 4>(p, s); break;
     case 1: launch_mx<256, 128, 3, 4, 2>(p, s); break;

@@ -72,10 +72,50 @@ void launch_take_cols_f16(const float* x, long ldx, f16* y, long M, int C, hipSt
 // ---------------------------------------------------------------------------------------------------- GroupNorm
 // fp32 in -> (x - mean) * rstd * gamma + beta (-> SiLU) -> hi/lo pair out.  Statistics per (frame, group): per-thread
 // fp32 partial sums over <= a few hundred values, everything above that in fp64, fixed order (deterministic).
-// Geometry: nvec = C/4 float4 vectors per row (<= 256), 256/nvec rows per iteration, grid (nchunk, T).
 struct Gn32P { const float* X; f16* Y; int T, HW, C, G; float eps; int silu; const f16* gamma; const f16* beta; double* part; float* mr; };
 
+// Geometry: nv = C/8 eight-channel vectors per row (two 16-byte loads, one 16-byte store per plane), 256/nv rows per iteration.
 __global__ __launch_bounds__(256) void k_gn32_stats(const Gn32P p, int nchunk, int rpc) {
+  __shared__ double rs[256], rq[256];
+  const int nv = p.C / 8, rpi = 256 / nv, tid = threadIdx.x;
+  const int rsub = tid / nv, v = tid - rsub * nv;
+  const int t = blockIdx.y, r0 = blockIdx.x * rpc, r1 = min(r0 + rpc, p.HW);
+  float s = 0.f, q = 0.f;
+  if (rsub < rpi) {
+    const float* base = p.X + (long)t * p.HW * p.C + v * 8;
+    int r = r0 + rsub;
+    for (; r + rpi < r1; r += 2 * rpi) {          // two rows = four 16-byte loads in flight
+      f32x4 x[4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) { x[2 * u] = *(const f32x4*)(base + (long)(r + u * rpi) * p.C); x[2 * u + 1] = *(const f32x4*)(base + (long)(r + u * rpi) * p.C + 4); }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s += x[u][e]; q += x[u][e] * x[u][e]; }
+    }
+    for (; r < r1; r += rpi) {
+      const f32x4 a = *(const f32x4*)(base + (long)r * p.C), b = *(const f32x4*)(base + (long)r * p.C + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s += a[e] + b[e]; q += a[e] * a[e] + b[e] * b[e]; }
+    }
+  }
+  rs[tid] = (rsub < rpi) ? (double)s : 0.0; rq[tid] = (rsub < rpi) ? (double)q : 0.0;
+  __syncthreads();
+  // group g owns channels [g*cpg, (g+1)*cpg): cpg is a multiple of 4; an 8-channel vector may straddle two groups only when cpg == 4
+  const int cpg = p.C / p.G;
+  if (tid < p.G) {
+    double a = 0.0, b = 0.0;
+    if (cpg % 8 == 0) {
+      const int vpg = cpg / 8;
+      for (int rr = 0; rr < rpi; ++rr)
+        for (int k = 0; k < vpg; ++k) { a += rs[rr * nv + tid * vpg + k]; b += rq[rr * nv + tid * vpg + k]; }
+    }
+    double* d = p.part + (((long)t * nchunk + blockIdx.x) * p.G + tid) * 2;
+    d[0] = a; d[1] = b;
+  }
+}
+// cpg == 4: the 8-channel vectors straddle two groups - the statistics pass uses 4-channel vectors instead
+__global__ __launch_bounds__(256) void k_gn32_stats4(const Gn32P p, int nchunk, int rpc) {
   __shared__ double rs[256], rq[256];
   const int nv = p.C / 4, rpi = 256 / nv, tid = threadIdx.x;
   const int rsub = tid / nv, v = tid - rsub * nv;
@@ -84,7 +124,7 @@ __global__ __launch_bounds__(256) void k_gn32_stats(const Gn32P p, int nchunk, i
   if (rsub < rpi) {
     const float* base = p.X + (long)t * p.HW * p.C + v * 4;
     int r = r0 + rsub;
-    for (; r + 3 * rpi < r1; r += 4 * rpi) {          // four rows' loads in flight
+    for (; r + 3 * rpi < r1; r += 4 * rpi) {
       f32x4 x[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) x[u] = *(const f32x4*)(base + (long)(r + u * rpi) * p.C);
@@ -101,7 +141,7 @@ __global__ __launch_bounds__(256) void k_gn32_stats(const Gn32P p, int nchunk, i
   }
   rs[tid] = (rsub < rpi) ? (double)s : 0.0; rq[tid] = (rsub < rpi) ? (double)q : 0.0;
   __syncthreads();
-  const int cpg = p.C / p.G, vpg = cpg / 4;
+  const int vpg = (p.C / p.G) / 4;
   if (tid < p.G) {
     double a = 0.0, b = 0.0;
     for (int rr = 0; rr < rpi; ++rr)
@@ -128,41 +168,49 @@ __global__ __launch_bounds__(256) void k_gn32_finalize(const Gn32P p, int nchunk
 }
 
 __global__ __launch_bounds__(256) void k_gn32_apply(const Gn32P p, int rpc) {
-  const int nv = p.C / 4, rpi = 256 / nv, tid = threadIdx.x;
+  const int nv = p.C / 8, rpi = 256 / nv, tid = threadIdx.x;
   const int rsub = tid / nv, v = tid - rsub * nv;
   if (rsub >= rpi) return;
   const int t = blockIdx.y, r0 = blockIdx.x * rpc, r1 = min(r0 + rpc, p.HW);
-  const int c = v * 4, g = c / (p.C / p.G);
-  const float mean = p.mr[((long)t * p.G + g) * 2], rstd = p.mr[((long)t * p.G + g) * 2 + 1];
-  float ga[4], be[4];
+  const int c = v * 8, cpg = p.C / p.G;
+  float mean[8], ga[8], be[8];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { ga[e] = rstd * (float)p.gamma[c + e]; be[e] = (float)p.beta[c + e]; }
-  auto emit = [&](long m, const f32x4 x) {
-    f32x4 y;
+  for (int e = 0; e < 8; ++e) {
+    const int g = (c + e) / cpg;
+    mean[e] = p.mr[((long)t * p.G + g) * 2];
+    ga[e] = p.mr[((long)t * p.G + g) * 2 + 1] * (float)p.gamma[c + e]; be[e] = (float)p.beta[c + e];
+  }
+  auto emit = [&](long m, const f32x4 xa, const f32x4 xb) {
+    f16x8 hi, lo;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float f = (x[e] - mean) * ga[e] + be[e];
-      if (p.silu) f = f / (1.0f + expf(-f));
-      y[e] = f;
+    for (int e = 0; e < 8; ++e) {
+      float f = ((e < 4 ? xa[e] : xb[e - 4]) - mean[e]) * ga[e] + be[e];
+      if (p.silu) f = f / (1.0f + __expf(-f));
+      const f16 h = (f16)f;
+      hi[e] = h; lo[e] = (f16)(f - (float)h);
     }
-    h4 hi, lo;
-    split4(y, hi, lo);
-    *(h4*)(p.Y + m * 2 * p.C + c) = hi;
-    *(h4*)(p.Y + m * 2 * p.C + p.C + c) = lo;
+    *(f16x8*)(p.Y + m * 2 * p.C + c) = hi;
+    *(f16x8*)(p.Y + m * 2 * p.C + p.C + c) = lo;
   };
   int r = r0 + rsub;
-  for (; r + 3 * rpi < r1; r += 4 * rpi) {            // four rows' loads in flight
+  for (; r + rpi < r1; r += 2 * rpi) {              // two rows = four 16-byte loads in flight
     f32x4 x[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) x[u] = *(const f32x4*)(p.X + ((long)t * p.HW + r + u * rpi) * p.C + c);
+    for (int u = 0; u < 2; ++u) {
+      const float* src = p.X + ((long)t * p.HW + r + u * rpi) * p.C + c;
+      x[2 * u] = *(const f32x4*)src; x[2 * u + 1] = *(const f32x4*)(src + 4);
+    }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) emit((long)t * p.HW + r + u * rpi, x[u]);
+    for (int u = 0; u < 2; ++u) emit((long)t * p.HW + r + u * rpi, x[2 * u], x[2 * u + 1]);
   }
-  for (; r < r1; r += rpi) emit((long)t * p.HW + r, *(const f32x4*)(p.X + ((long)t * p.HW + r) * p.C + c));
+  for (; r < r1; r += rpi) {
+    const float* src = p.X + ((long)t * p.HW + r) * p.C + c;
+    emit((long)t * p.HW + r, *(const f32x4*)src, *(const f32x4*)(src + 4));
+  }
 }
 
 static inline void gn32_chunks(int T, int HW, int C, int& nchunk, int& rpc) {
-  const int rpi = 256 / (C / 4);
+  const int rpi = 256 / (C / 8);
   rpc = std::max((HW + cdiv(2048, T) - 1) / cdiv(2048, T), 4 * rpi);
   nchunk = cdiv(HW, rpc);
 }
@@ -174,13 +222,14 @@ size_t gn32_ws_bytes(int T, int HW, int C, int G) {
 // X fp32 [T*HW, C] -> Y fp16 pair [T*HW, 2C]; ws from gn32_ws_bytes
 void launch_gn32_pair(const float* X, f16* Y, int T, int HW, int C, int G, float eps, int silu, const f16* gamma, const f16* beta,
                       void* ws, hipStream_t s) {
-  UG_REQUIRE(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0, "gn32: C/4 must divide 256");
+  UG_REQUIRE(C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0, "gn32: C/8 must divide 256");
   UG_REQUIRE(C % G == 0 && (C / G) % 4 == 0 && G <= 256, "gn32: channels per group must be a multiple of 4");
   int nchunk, rpc;
   gn32_chunks(T, HW, C, nchunk, rpc);
   Gn32P p; p.X = X; p.Y = Y; p.T = T; p.HW = HW; p.C = C; p.G = G; p.eps = eps; p.silu = silu; p.gamma = gamma; p.beta = beta;
   p.part = (double*)ws; p.mr = (float*)((char*)ws + (size_t)T * nchunk * G * 2 * sizeof(double));
-  hipLaunchKernelGGL(k_gn32_stats, dim3(nchunk, T), dim3(256), 0, s, p, nchunk, rpc);
+  if ((C / G) % 8 == 0) hipLaunchKernelGGL(k_gn32_stats, dim3(nchunk, T), dim3(256), 0, s, p, nchunk, rpc);
+  else hipLaunchKernelGGL(k_gn32_stats4, dim3(nchunk, T), dim3(256), 0, s, p, nchunk, rpc);
   hipLaunchKernelGGL(k_gn32_finalize, dim3(T), dim3(256), 0, s, p, nchunk);
   hipLaunchKernelGGL(k_gn32_apply, dim3(nchunk, T), dim3(256), 0, s, p, rpc);
   UG_CHECK(hipGetLastError());
