@@ -233,6 +233,8 @@ def main():
                                "kernel": "gemm_kernel<...> + gemm_ws_kernel<...> + gemm_ldr_kernel<...> (all linear / 3x3 / 1x1 / temporal-conv / attention GEMM launches)",
                                "launches": g_calls, "avg_launch_us": round(g_ms * 1000.0 / max(g_calls, 1), 2),
                                "algorithmic_tflop": round(g_fl / 1e12, 2),
+                               "note": "algorithmic FLOPs (SURVEY 8d): a nearest-2x upsample + 3x3 conv is credited its 9-tap FLOPs although the "
+                                       "sub-pixel kernel (gemm_conv_up2x2) executes 4 taps - its apparent > 1 PFLOP/s rates in per-shape tables are not MFMA rates",
                                "algorithmic_bytes_per_launch": round(sum(v.get("bytes", 0) for v in gem.values()) / max(g_calls, 1))}
             # HBM traffic of the same kernel family: rocprofv3 PMC passes collected by the committed script tools/pmc_traffic.sh
             # (FETCH_SIZE and WRITE_SIZE in separate passes, counters only) -> profiles/r02_pmc_traffic_gemm.json, which

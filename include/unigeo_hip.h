@@ -87,7 +87,7 @@ int ug_dc_set_inputs(ug_ctx* ctx, const float* frames_thwc, int T, int H, int W,
                      const float* noise_aug, const float* intrinsics_t33);
 int ug_dc_run(ug_ctx* ctx, int steps, int decode_chunk, int with_normals);
 /* Long-video mode of the pipeline call (`window_size` / `overlap` of model/depthcrafter.py:87-88, which the reference pins to
- * len(frames) / 25, i.e. OFF): latent sliding windows of `window` (<= 64) frames with `overlap` re-noised + cross-faded frames,
+ * len(frames) / 25, i.e. OFF): latent sliding windows of `window` (<= 128) frames with `overlap` re-noised + cross-faded frames,
  * restated from upstream DepthCrafter's published pipeline (UNPINNED).  window == 0 or >= T is ug_dc_run.  The first `window`
  * frames of the noise passed to ug_dc_set_inputs are the window noise (rotated by `overlap` frames per window, as upstream). */
 int ug_dc_run_windows(ug_ctx* ctx, int steps, int decode_chunk, int with_normals, int window, int overlap);
@@ -101,6 +101,7 @@ int ug_set_vae_encode_fp32(ug_ctx* ctx, int on);
  * FeedForward module inside the un-vendored UNet): ug_set_ff_fused(0) falls back to two GEMM launches; ug_op_ff evaluates
  * c0 * (GEGLU(X W1^T + b1) W2^T + b2) + c1 * R1 on [M, C] with either implementation (W1 [8C][C], b1 [8C], W2 [C][4C] in diffusers order). */
 int ug_set_ff_fused(ug_ctx* ctx, int on);
+int ug_bench_flash(ug_ctx* ctx, int B, int H, int S, int variant, int iters, float* us_out);   /* flash-attention A/B on device-resident random data */
 int ug_bench_ff(ug_ctx* ctx, int M, int C, int fused, int iters, float* us_out);
 int ug_op_ff(ug_ctx* ctx, const float* X, int M, int C, const float* W1, const float* b1, const float* W2, const float* b2, const float* R1,
              float c0, float c1, int fused, float* out);
@@ -186,6 +187,7 @@ int ug_bench_groupnorm(ug_ctx* ctx, int C0, int C1, int T, int HW, int temporal,
 int ug_bench_gemm(ug_ctx* ctx, int M, int N, int K, int conv, int T, int Hi, int Wi, int C0, int C1, int kt, int k,
                   int stride, int ups, int cfg, int split, int iters, float* ms_out);
 int ug_tune_force(int cfg, int split);
+int ug_tune_flash(int variant);   /* A/B knob: body of the flash-attention KV tile (0 = per-32-key softmax steps, 1 = one step per 64 keys) */
 
 /* HIP-event profiling of everything launched between begin and end; end returns a JSON
  * object {kernel_family: {ms, calls, flops, bytes}} valid until the next call on ctx. */

@@ -65,6 +65,9 @@ def test_plugin_contract(tiny_plugin):
     np.testing.assert_allclose(n.norm(dim=-1).numpy(), 1.0, atol=1e-4)
     out2 = tiny_plugin.forward(data)                      # same clip index -> same noise -> bit-identical (deterministic kernels)
     assert torch.equal(out2["pred_depths"], d) and torch.equal(out2["pred_normals"], n)
+    # prepare_output keeps the reference's (depths, data) signature (model/depthcrafter.py:48) and reproduces forward's normals
+    po = tiny_plugin.prepare_output(list(d.numpy()), data)
+    assert torch.equal(po["pred_depths"], d) and torch.allclose(po["pred_normals"], n, atol=1e-6)
     data["_index"] = 8                                    # another clip draws independent noise (reference: fresh RNG draws)
     assert not torch.equal(tiny_plugin.forward(data)["pred_depths"], d)
     with pytest.raises(ValueError):

@@ -160,8 +160,9 @@ def test_pipeline_edge_cases(tiny, T, H, W, steps, chunk):
 
 
 def test_frame_count_limits(tiny):
-    """Maximum clip length (64 frames: one temporal-attention tile) runs and matches the oracle; one more frame, an empty clip and
-    a ragged noise tensor are refused with a message instead of being truncated or padded."""
+    """A 64-frame clip and a 100-frame clip (3- / 4-block temporal-attention tiles; the limit of one denoising window is 128 frames,
+    upstream DepthCrafter's default window is 110) run and match the oracle; 129 frames, an empty clip and a ragged noise tensor are
+    refused with a message instead of being truncated or padded."""
     from oracle.pipeline import run_pipeline
     from unigeo_amd.pipeline import make_noise
     T, H, W = 64, 64, 64
@@ -171,10 +172,16 @@ def test_frame_count_limits(tiny):
     res = tiny["pipe"](frames, num_inference_steps=1, window_size=T, noise_latents=nl, noise_aug=na)
     ref = run_pipeline(tiny["unet"], tiny["vae"], tiny["clip"], frames, torch.from_numpy(nl), torch.from_numpy(na), steps=1, chunk=8)
     assert_abs(res.frames[0], ref, 1.5e-2, "tiny pipeline, 64 frames")
-    big = rng.uniform(0, 1, (65, H, W, 3)).astype(np.float32)
-    nl2, na2 = make_noise(65, H, W, seed=1)
+    T2 = 100
+    f2 = rng.uniform(0, 1, (T2, H, W, 3)).astype(np.float32)
+    nl3, na3 = make_noise(T2, H, W, seed=2)
+    res2 = tiny["pipe"](f2, num_inference_steps=1, window_size=T2, noise_latents=nl3, noise_aug=na3)
+    ref2 = run_pipeline(tiny["unet"], tiny["vae"], tiny["clip"], f2, torch.from_numpy(nl3), torch.from_numpy(na3), steps=1, chunk=8)
+    assert_abs(res2.frames[0], ref2, 1.5e-2, "tiny pipeline, 100 frames")
+    big = rng.uniform(0, 1, (129, H, W, 3)).astype(np.float32)
+    nl2, na2 = make_noise(129, H, W, seed=1)
     with pytest.raises((RuntimeError, ValueError, NotImplementedError)):
-        tiny["pipe"](big, num_inference_steps=1, window_size=65, noise_latents=nl2, noise_aug=na2)
+        tiny["pipe"](big, num_inference_steps=1, window_size=129, noise_latents=nl2, noise_aug=na2)
     with pytest.raises((RuntimeError, ValueError)):
         tiny["pipe"](frames[:0], num_inference_steps=1, window_size=1, noise_latents=nl[:, :0], noise_aug=na[:0])
     with pytest.raises((RuntimeError, ValueError)):

@@ -30,4 +30,5 @@ for k, v in rows[:70]:
     tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["flops"] else 0
     gb = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["bytes"] else 0
     print(f"{k:48s} {v['ms']:9.2f} ms {v['calls']:5d} calls {v['ms']*1000/v['calls']:9.1f} us/call {tf:8.1f} TF/s {gb:8.0f} GB/s")
+print("note: gemm_conv_up2x2 rows are credited the 9-tap algorithmic FLOPs of upsample+conv while executing 4 taps - not MFMA rates")
 json.dump(prof, open("gpurun_out/shapes.json", "w"))

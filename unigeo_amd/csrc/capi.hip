@@ -500,6 +500,26 @@ int ug_op_ff(ug_ctx* x, const float* X, int M, int C, const float* W1, const flo
     down16(c, dO, out, (long)M * C);
   });
 }
+int ug_bench_flash(ug_ctx* x, int B, int H, int S, int variant, int iters, float* us_out) {
+  UG_TRY(x, {
+    Ctx& c = x->c; Scope sc(c);
+    const long M = (long)B * S; const int C = H * 64;
+    f16* qkv = c.ws.get<f16>(M * 3 * C); f16* o = c.ws.get<f16>(M * C);
+    launch_fill_random(qkv, M * 3 * C, 7, c.stream);
+    FlashP p; p.Q = qkv; p.K = qkv + C; p.V = qkv + 2 * C; p.ldq = p.ldk = p.ldv = 3 * C; p.O = o; p.ldo = C; p.B = B; p.H = H; p.S = S; p.scale = 0.125f;
+    flash_set_variant(variant);
+    launch_flash_attn64(p, c.stream); launch_flash_attn64(p, c.stream);
+    hipEvent_t e0, e1; UG_CHECK(hipEventCreate(&e0)); UG_CHECK(hipEventCreate(&e1));
+    UG_CHECK(hipEventRecord(e0, c.stream));
+    for (int i = 0; i < iters; ++i) launch_flash_attn64(p, c.stream);
+    UG_CHECK(hipEventRecord(e1, c.stream));
+    UG_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f; UG_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    flash_set_variant(0);
+    *us_out = ms * 1000.f / iters;
+  });
+}
 int ug_bench_ff(ug_ctx* x, int M, int C, int fused, int iters, float* us_out) {
   UG_TRY(x, {
     Ctx& c = x->c; Scope sc(c);
@@ -693,6 +713,7 @@ int ug_op_attention_generic(ug_ctx* x, const float* qkv, int B, int S, int H, in
 }
 
 int ug_tune_force(int cfg, int split) { gemm_force(cfg, split); return 0; }
+int ug_tune_flash(int variant) { flash_set_variant(variant); return 0; }
 
 // GEMM / conv microbenchmark on device-resident pseudo-random data: average ms per launch over `iters`.
 int ug_bench_gemm(ug_ctx* x, int M, int N, int K, int conv, int T, int Hi, int Wi, int C0, int C1, int kt, int k,

@@ -126,9 +126,10 @@ struct FlashP {
   int Sk = 0; int kv_shared = 0;
 };
 void launch_flash_attn64(const FlashP& p, hipStream_t s);
+void flash_set_variant(int v);   // tuning aid: A/B variants of the KV-tile body (tools/bench_flash.py)
 
 // Temporal self-attention: for every pixel p and head h, sequence over the T frames
-// (row of frame t = t*HW + p), head_dim 64, T <= 64 (BASELINE config 5 uses 50-frame clips).
+// (row of frame t = t*HW + p), head_dim 64, T <= 128 (BASELINE config 5 uses 50-frame clips; upstream DepthCrafter's default window is 110 frames).
 struct TemporalAttnP {
   const f16* Q; const f16* K; const f16* V; long ld;
   f16* O; long ldo;

@@ -1210,7 +1210,7 @@ f16* clip_embed(Ctx& c, const f16* video_m11, int T, int H, int W) {
 void dc_set_inputs(Ctx& c, const float* frames, int T, int H, int W, const float* noise_lat, const float* noise_aug,
                    const float* K33) {
   UG_REQUIRE(H % 64 == 0 && W % 64 == 0, "height and width must be multiples of 64 (VAE /8, UNet /8)");
-  UG_REQUIRE(T >= 1 && T <= 4096, "1..4096 frames (at most 64 per denoising window)");
+  UG_REQUIRE(T >= 1 && T <= 4096, "1..4096 frames (at most 128 per denoising window)");
   if (c.io_ready) { c.ws.release(c.io_mark); c.io_ready = false; }
   c.io_mark = c.ws.mark();
   c.T = T; c.H = H; c.W = W;
@@ -1251,8 +1251,8 @@ void dc_run(Ctx& c, int steps, int chunk, int with_normals, int window, int over
   UG_REQUIRE(steps >= 1 && chunk >= 1, "steps/chunk");
   const int T = c.T, H = c.H, W = c.W, h = H / 8, w = W / 8;
   const bool windows = window > 0 && window < T;
-  if (windows) UG_REQUIRE(window <= 64 && overlap >= 0 && overlap < window, "window must be <= 64 frames and overlap < window");
-  else UG_REQUIRE(T <= 64, "more than 64 frames need latent sliding windows (window <= 64)");
+  if (windows) UG_REQUIRE(window <= 128 && overlap >= 0 && overlap < window, "window must be <= 128 frames and overlap < window");
+  else UG_REQUIRE(T <= 128, "more than 128 frames need latent sliding windows (window <= 128)");
   const long px = (long)T * H * W, lp = (long)T * h * w;
   const size_t mk = c.ws.mark();
   // 1. inputs -> fp16, [-1,1], noise augmentation

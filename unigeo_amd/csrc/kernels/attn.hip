@@ -132,7 +132,80 @@ __device__ __forceinline__ void fa_tile(const f16* kt, const f16* vt, const f16x
   }
 }
 
-__global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const FlashP p) {
+// Variant of fa_tile: the scores of BOTH 32-key blocks are computed first (two interleaved accumulate chains, so a dependent
+// MFMA never issues back to back), then ONE online-softmax update over the 64 keys, then the PV products of both blocks.
+template <bool MASK>
+__device__ __forceinline__ void fa_tile_wide(const f16* kt, const f16* vt, const f16x8 (&qf)[FA_QB][4], int lane, int kv0, int S,
+                                             float sc, float (&m_run)[FA_QB], float (&l_run)[FA_QB], f32x16 (&o)[FA_QB][2]) {
+  const int qi = lane & 31, hh = lane >> 5;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int L = lane & 15, db = ((lane >> 4) & 1) * 16;
+  f32x16 s[2];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    f16x8 kf[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) { const int row = kb * 32 + qi; kf[kb] = *(const f16x8*)(kt + row * 64 + (((c * 2 + hh) ^ kswz(row)) * 8)); }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb], qf[0][c], c == 0 ? zero16 : s[kb], 0, 0, 0);
+  }
+  float mx = -1e30f;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (MASK) {
+        const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (key >= S) s[kb][r] = -1e30f;
+      }
+      mx = fmaxf(mx, s[kb][r]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  const float m_new = fmaxf(m_run[0], mx * sc);
+  if (!__all(m_new == m_run[0])) {
+    const float alpha = __builtin_amdgcn_exp2f(m_run[0] - m_new);
+    l_run[0] *= alpha;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[0][dt][r] *= alpha;
+    m_run[0] = m_new;
+  }
+  f16x8 pb[2][2];
+  float ps = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sc, -m_run[0]));
+      ps += e;
+      pb[kb][r >> 3][r & 7] = (f16)e;
+    }
+  l_run[0] += ps;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        f16x8 va;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int vrow = kb * 32 + 16 * a + 8 * h + 4 * hh + (L >> 2);
+          const int col = dt * 32 + db + (L & 3) * 4;
+          const int chunk = (col >> 3) ^ vswz(vrow);
+          const f16x4 t = lds_tr16(vt + vrow * 64 + chunk * 8 + (col & 7));
+          va[4 * h + 0] = t[0]; va[4 * h + 1] = t[1]; va[4 * h + 2] = t[2]; va[4 * h + 3] = t[3];
+        }
+        o[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pb[kb][a], o[0][dt], 0, 0, 0);
+      }
+}
+
+static int g_fa_wide = 0;   // A/B knob (ug_tune_flash): 1 = fa_tile_wide
+void flash_set_variant(int v) { g_fa_wide = v; }
+
+template <bool WIDE>
+__global__ __launch_bounds__(256, 3) void flash_attn64_kernel(const FlashP p) {
   __shared__ __attribute__((aligned(16))) f16 lds[FA_NST * 2 * FA_KV * 64];  // [slot][K|V][64][64]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -205,8 +278,13 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const FlashP p) {
     if (++ld == FA_NST) ld = 0;
     const f16* kt = lds + buf * (2 * FA_KV * 64);
     const f16* vt = kt + FA_KV * 64;
-    if (t < nfull) fa_tile<false>(kt, vt, qf, lane, t * FA_KV, Sk, sc, m_run, l_run, o);
-    else fa_tile<true>(kt, vt, qf, lane, t * FA_KV, Sk, sc, m_run, l_run, o);
+    if (WIDE) {
+      if (t < nfull) fa_tile_wide<false>(kt, vt, qf, lane, t * FA_KV, Sk, sc, m_run, l_run, o);
+      else fa_tile_wide<true>(kt, vt, qf, lane, t * FA_KV, Sk, sc, m_run, l_run, o);
+    } else {
+      if (t < nfull) fa_tile<false>(kt, vt, qf, lane, t * FA_KV, Sk, sc, m_run, l_run, o);
+      else fa_tile<true>(kt, vt, qf, lane, t * FA_KV, Sk, sc, m_run, l_run, o);
+    }
     if (++buf == FA_NST) buf = 0;
   }
 #pragma unroll
@@ -233,14 +311,15 @@ void launch_flash_attn64(const FlashP& p, hipStream_t s) {
   UG_REQUIRE(p.S >= 1 && p.B >= 1 && p.H >= 1, "flash attention shape");
   UG_REQUIRE(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0, "flash attention strides");
   dim3 grid(cdiv(p.S, 128 * FA_QB), p.H, p.B);
-  hipLaunchKernelGGL(flash_attn64_kernel, grid, dim3(256), 0, s, p);
+  if (g_fa_wide) hipLaunchKernelGGL(flash_attn64_kernel<true>, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(flash_attn64_kernel<false>, grid, dim3(256), 0, s, p);
   UG_CHECK(hipGetLastError());
 }
 
 // ------------------------------------------------------------------------------------------
 // temporal attention: sequence = the T frames of one pixel; one wave per (pixel, head).
 // ------------------------------------------------------------------------------------------
-// NB = number of 32-frame blocks (1: T <= 32, 2: T <= 64).  Each wave handles one (pixel, head): all NB*32 key rows'
+// NB = number of 32-frame blocks (1: T <= 32 ... 4: T <= 128).  Each wave handles one (pixel, head): all NB*32 key rows'
 // V slab sits in its private LDS region, every 32-query block sees all keys at once (plain softmax, no rescaling).
 template <int NB>
 __global__ __launch_bounds__(256) void temporal_attn64_kernel(const TemporalAttnP p) {
@@ -335,11 +414,13 @@ __global__ __launch_bounds__(256) void temporal_attn64_kernel(const TemporalAttn
 }
 
 void launch_temporal_attn64(const TemporalAttnP& p, hipStream_t s) {
-  UG_REQUIRE(p.T >= 1 && p.T <= 64, "temporal attention supports up to 64 frames per clip");
+  UG_REQUIRE(p.T >= 1 && p.T <= 128, "temporal attention supports up to 128 frames per denoising window");
   UG_REQUIRE(p.ld % 8 == 0 && p.ldo % 4 == 0, "temporal attention strides");
   dim3 grid(cdiv(p.HW, 4), p.H);
   if (p.T <= 32) hipLaunchKernelGGL(temporal_attn64_kernel<1>, grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(temporal_attn64_kernel<2>, grid, dim3(256), 0, s, p);
+  else if (p.T <= 64) hipLaunchKernelGGL(temporal_attn64_kernel<2>, grid, dim3(256), 0, s, p);
+  else if (p.T <= 96) hipLaunchKernelGGL(temporal_attn64_kernel<3>, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(temporal_attn64_kernel<4>, grid, dim3(256), 0, s, p);   // 64 KiB of LDS: upstream DepthCrafter's default 110-frame window
   UG_CHECK(hipGetLastError());
 }
 

@@ -51,10 +51,17 @@ class DepthCrafter:
         frames = [np.asarray(x).transpose(1, 2, 0).astype(np.uint8) for x in data["images"]]
         return np.stack(frames, axis=0).astype(np.float32) / 255.0
 
-    def prepare_output(self, depths, normals):
+    def prepare_output(self, depthcrafter_depths, data, _device_normals=None):
+        """Reference signature (model/depthcrafter.py:48): list / array of [H,W] depth maps + the sample dict (``intrinsics``) ->
+        {'pred_depths' [Nf,H,W], 'pred_normals' [Nf,H,W,3]} in OpenGL camera coordinates.  The back-projection + surface-normal
+        fit + y/z flip of :51-59 run on the GPU (``k_normals``); ``forward`` passes the normals ``ug_dc_run`` already produced."""
         import torch
-        return {"pred_depths": torch.from_numpy(np.ascontiguousarray(depths)).float(),
-                "pred_normals": torch.from_numpy(np.ascontiguousarray(normals)).float()}
+        depths = np.ascontiguousarray(np.stack([np.asarray(d, dtype=np.float32) for d in depthcrafter_depths], 0))
+        if _device_normals is None:
+            K = np.stack([np.asarray(k, dtype=np.float32).reshape(3, 3) for k in data["intrinsics"]], 0)
+            _device_normals = self.pipeline.engine.normals_from_depth(depths, K)
+        return {"pred_depths": torch.from_numpy(depths).float(),
+                "pred_normals": torch.from_numpy(np.ascontiguousarray(_device_normals)).float()}
 
     def forward(self, data):
         frames = self.prepare_input(data)
@@ -67,4 +74,4 @@ class DepthCrafter:
                             guidance_scale=1.0, num_inference_steps=self.num_inference_steps,
                             window_size=len(frames), overlap=25, track_time=False, seed=clip_seed,
                             intrinsics=K, with_normals=True)
-        return self.prepare_output(res.depth, res.normals)
+        return self.prepare_output(list(res.depth), data, _device_normals=res.normals)

@@ -92,8 +92,8 @@ class DepthCrafterPipelineHIP:
             raise ValueError("height and width must be multiples of 64")
         if guidance_scale > 1.0:
             raise NotImplementedError("classifier-free guidance is not on the reference path (guidance_scale=1.0)")
-        if T > window_size and window_size > 64:
-            raise ValueError("a denoising window holds at most 64 frames (temporal attention tile); pass window_size <= 64")
+        if T > window_size and window_size > 128:
+            raise ValueError("a denoising window holds at most 128 frames (temporal attention tile); pass window_size <= 128")
         if T > window_size and not 0 <= overlap < window_size:
             raise ValueError("overlap must be in [0, window_size)")
         if abs(noise_aug_strength - 0.02) > 1e-9:
