@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python tools/one_clip.py $STEPS --events gpurun_out/pmc_events.json > gpurun_out/pmc_events.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$C
-  timeout 1500 rocprofv3 --pmc $C --kernel-include-regex "gemm_(kernel|ldr_kernel|ws_kernel)" --output-format csv -d gpurun_out/pmc_$C -o pmc -- python tools/one_clip.py $STEPS > gpurun_out/pmc_$C.log 2>&1 || true
+  timeout 1500 rocprofv3 --pmc $C --kernel-include-regex "gemm_(kernel|ldr_kernel|ws_kernel)|ff_fused_kernel" --output-format csv -d gpurun_out/pmc_$C -o pmc -- python tools/one_clip.py $STEPS > gpurun_out/pmc_$C.log 2>&1 || true
 done
 python tools/pmc_summarise.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
 rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE   # tens of MB of per-dispatch rows; the summary carries their hashes

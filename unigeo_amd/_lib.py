@@ -475,7 +475,9 @@ class Engine:
         self._ck((self.lib.ug_profile_begin_shapes if shapes else self.lib.ug_profile_begin)(self.ctx))
 
     def profile_end(self):
-        return json.loads(self.lib.ug_profile_end(self.ctx).decode())
+        prof = json.loads(self.lib.ug_profile_end(self.ctx).decode())
+        self.last_profile_order = prof.pop("__order__", None)      # shapes=True: [[name, algorithmic bytes], ...] of the GEMM launches, in order
+        return prof
 
     def workspace_peak(self):
         return int(self.lib.ug_workspace_peak(self.ctx))

@@ -69,6 +69,7 @@ struct GemmP {
   // MX-fp8 dense path (launch_gemm_mx8): A0 / W point at OCP e4m3 bytes ([M][K] / [N][K], K % 128 == 0); sa / sw hold the e8m0 block
   // scales, four per dword (K blocks of 32 inside one 128-wide K step), K-step-major: sa[kstep * ld_sa + m], sw[kstep * ld_sw + n]
   const unsigned* sa; const unsigned* sw; long ld_sa, ld_sw;
+  int group_m;           // tile walk: 0 / 1 = row-major, g > 1 = g M-tiles x all N tiles column by column (set by launch_gemm; see tile_coord)
 };
 void launch_gemm_mx8(const GemmP& p, hipStream_t s);   // dense only; C0 = lda and ldw in BYTES (= elements)
 // fp16 [M, K] (row stride ldx) -> e4m3 bytes [M, K] + e8m0 scales (layout above, ld_s >= round_up(M, 256)); K % 128 == 0

@@ -52,10 +52,22 @@ std::string prof_end(Ctx& c) {
     Agg& a = agg[r.name]; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes; a.calls++;
     (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
   }
-  c.prof.clear();
   std::ostringstream o;
   o << "{";
   bool first = true;
+  if (c.prof_shapes) {   // launch order of the GEMM-family records (joined with rocprofv3's per-dispatch counters by tools/pmc_per_shape.py)
+    o << "\"__order__\":[";
+    bool f2 = true;
+    for (auto& r : c.prof) {
+      if (r.name.compare(0, 5, "gemm_") != 0) continue;
+      if (!f2) o << ",";
+      f2 = false;
+      o << "[\"" << r.name << "\"," << r.bytes << "]";
+    }
+    o << "]";
+    first = false;
+  }
+  c.prof.clear();
   for (auto& kv : agg) {
     if (!first) o << ",";
     first = false;

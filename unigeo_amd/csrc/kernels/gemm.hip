@@ -63,6 +63,21 @@ template <int BK> __device__ __forceinline__ int swz(int row) {
   else return (row >> 2) & 3;            // 64-B rows, 4 rows per bank row
 }
 
+// Tile id -> (tm, tn).  group_m <= 1: row-major (all N tiles of one M tile are neighbours: the workgroups of an XCD share ONE
+// activation panel - right for im2col, whose A operand is re-read per tap, and for weights that fit the 4 MiB L2).  group_m = g > 1:
+// ids walk g M-tiles x all N tiles column by column, so the ~32 tiles an XCD works on at a time form a g x (32/g) block and touch
+// g + 32/g operand panels instead of 1 + 32 - for dense layers with weights far larger than the L2 the row-major walk re-fetched the
+// whole weight matrix once per M tile (profiles/r02_pmc_traffic_per_shape.txt: 4800x10240x1280 read 524 MB for 88 MB of operands).
+__device__ __forceinline__ void tile_coord(int tile, int ntm, int ntn, int group_m, int& tm, int& tn) {
+  if (group_m <= 1) { tm = tile / ntn; tn = tile - tm * ntn; return; }
+  const int per = group_m * ntn;
+  const int grp = tile / per, local = tile - grp * per;
+  const int first = grp * group_m;
+  const int gm = min(ntm - first, group_m);
+  tn = local / gm;
+  tm = first + (local - tn * gm);
+}
+
 // waves per SIMD the LDS footprint allows (workgroups per CU x waves per workgroup / 4 SIMDs): handed to
 // __launch_bounds__ so the register allocator does not trade that occupancy away.
 template <int BM, int BN, int BK, int NST, int WMW, int WNW> struct GemmOcc {
@@ -318,7 +333,7 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
 
   int ld_m0 = 0, ld_n0 = 0;   // MX: origin of the tile being fetched (scale rows)
   auto setup_tile = [&](int tile) {
-    const int tn = tile % ntn, tm = tile / ntn;
+    int tm, tn; tile_coord(tile, ntm, ntn, p.group_m, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     ld_m0 = m0; ld_n0 = n0;
 #pragma unroll
@@ -583,7 +598,7 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
     // ---- tile finished: epilogue (the next tile's operands keep streaming into the ring meanwhile) ----
     drain = true;
     const int tile = wslot + ti * nwg;
-    tile_epilogue<MT, NT, WTM, WTN>(p, acc, (tile / ntn) * BM, (tile % ntn) * BN, wm, wn, lane, out_off);
+    { int etm, etn; tile_coord(tile, ntm, ntn, p.group_m, etm, etn); tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
   }
 }
 
@@ -655,7 +670,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ldr_kernel(const GemmP p) {
   const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, (int)SENT, 0x00020000);
 
   auto setup_tile = [&](int tile) {
-    const int tn = tile % ntn, tm = tile / ntn;
+    int tm, tn; tile_coord(tile, ntm, ntn, p.group_m, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 #pragma unroll
     for (int l = 0; l < LA; ++l) {
@@ -812,7 +827,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ldr_kernel(const GemmP p) {
     cp_ks = 0;
     const int tile = wslot + (cp_ti++) * nwg;
     drain = true;
-    tile_epilogue<MT, NT, WTM, WTN>(p, acc, (tile / ntn) * BM, (tile % ntn) * BN, wm, wn, lane, out_off);
+    { int etm, etn; tile_coord(tile, ntm, ntn, p.group_m, etm, etn); tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
   }
 }
 
@@ -904,7 +919,7 @@ __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(const GemmP p) {
     auto issue = [&]() {
       if (ld_ks == 0) {
         const int tile = wslot + ld_ti * nwg;
-        const int tn = tile % ntn, tm = tile / ntn;
+        int tm, tn; tile_coord(tile, ntm, ntn, p.group_m, tm, tn);
         const int m0 = tm * BM, n0 = tn * BN;
 #pragma unroll
         for (int l = 0; l < LA; ++l) {
@@ -1059,7 +1074,7 @@ __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(const GemmP p) {
     if (++cp_ks == nk) {
       cp_ks = 0;
       const int tile = wslot + (cp_ti++) * nwg;
-      tile_epilogue<MT, NT, WTM, WTN>(p, acc, (tile / ntn) * BM, (tile % ntn) * BN, wm, wn, lane, out_off);
+      { int etm, etn; tile_coord(tile, ntm, ntn, p.group_m, etm, etn); tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all fragment reads of this slot are done before it is handed back
     UG_STAMP(2);
@@ -1267,6 +1282,14 @@ void launch_gemm_mx8(const GemmP& p0, hipStream_t s) {
   // workgroups ran below the fp16 kernel)
   const long t256 = (long)cdiv(p.M, 256) * cdiv(p.N, 256), t128n = (long)cdiv(p.M, 256) * cdiv(p.N, 128);
   const int pick = force >= 100 ? force - 100 : (t256 >= 200 ? 0 : t128n >= 200 ? 1 : 2);
+  {   // grouped tile walk when the fp8 weights exceed the L2 (same rule as pick_group_m)
+    const int bm = pick == 2 ? 128 : 256, bn = pick == 0 ? 256 : 128, percu = pick == 2 ? 2 : 1;
+    const int ntm = cdiv(p.M, bm), ntn = cdiv(p.N, bn);
+    int g = 1;
+    if (!(g_knobs & 32) && (double)p.N * p.K * 2.0 > 3.0 * (1 << 20) && ntm >= 2 && ntn >= 2)
+      while (g * 2 <= ntm && (double)(g * 2) * (g * 2) <= 32.0 * percu * bn / bm * 1.5) g *= 2;
+    p.group_m = g;
+  }
   switch (pick) {
     case 0: launch_mx<256, 256, 2, 2, 4>(p, s); break;
     case 1: launch_mx<256, 128, 3, 4, 2>(p, s); break;
@@ -1337,6 +1360,29 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
   *cfg_out = cfg; *split_out = split;
 }
 
+// Tile-walk grouping for dense layers whose weights do not fit the per-XCD L2 (tile_coord): the ~P tiles an XCD processes at a time
+// should touch as few operand panels as possible: a x b = P with a * BM ~ b * BN.
+static int pick_group_m(const GemmP& p, int cfg, int batch, int split) {
+  if ((p.conv && (g_knobs & 64)) || batch > 1 || split > 1 || (g_knobs & 32)) return 1;   // knobs: 32 = row-major walk everywhere, 64 = row-major for im2col (A/B)
+  if ((double)p.N * p.K * 2.0 <= 3.0 * (1 << 20)) return 1;          // weights stay L2 resident: share the activation panel instead
+  int bm = 256, bn = 128, percu = 1;
+  switch (cfg) {
+    case 0: bm = 128; bn = 128; percu = 2; break;
+    case 1: case 3: bm = 128; bn = 64; percu = cfg == 1 ? 3 : 2; break;
+    case 12: bm = 64; bn = 64; percu = 5; break;
+    case 14: case 34: bm = 256; bn = 64; percu = 2; break;
+    case 15: case 35: bm = 256; bn = 256; break;
+    case 60: bm = 256; bn = 160; break;
+    default: break;                                                    // 4, 8, 19, 39, 54, 59: 256 x 128
+  }
+  const int ntm = cdiv(p.M, bm), ntn = cdiv(p.N, bn);
+  if (ntm < 2 || ntn < 2) return 1;
+  const double P = 32.0 * percu;
+  int g = 1;
+  while (g * 2 <= ntm && (double)(g * 2) * (g * 2) <= P * bn / bm * 1.5) g *= 2;   // nearest power of two to sqrt(P bn / bm)
+  return g;
+}
+
 void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
   GemmP p = p0;
   if (g_knobs & 2) p.flags |= UG_F_NOXCD;
@@ -1360,6 +1406,7 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
   if (p.flags & UG_F_GEGLU) UG_REQUIRE(cfg == 0 || cfg == 4 || cfg == 8 || cfg == 15 || cfg == 35 || cfg == 54, "GEGLU needs a 64-column wave tile");
   p.splitk = split;
   if (split > 1) UG_REQUIRE(p.partial != nullptr, "split-K needs a partial buffer");
+  p.group_m = pick_group_m(p, cfg, batch, split);
   launch_cfg(cfg, p, batch, s);
   if (split > 1) {
     const long nvec = (long)p.M * (p.N / 8);
