@@ -602,8 +602,9 @@ int ug_op_conv(ug_ctx* x, const float* x0, int C0, const float* x1, int C1, int 
     Ctx& c = x->c; Scope sc(c);
     const int I = C0 + C1, taps = kt * k * k;
     std::vector<float> wp((size_t)O * taps * I);
+    const bool kch = (I % 64 == 0) && taps > 1 && !getenv("UG_NO_KCHUNK");     // the engine's chunk-major K order (GemmP::kchunk)
     for (int o = 0; o < O; ++o) for (int i = 0; i < I; ++i) for (int tp = 0; tp < taps; ++tp)
-      wp[((size_t)o * taps + tp) * I + i] = weight[((size_t)o * I + i) * taps + tp];
+      wp[kch ? (((size_t)o * (I / 64) + i / 64) * taps + tp) * 64 + i % 64 : ((size_t)o * taps + tp) * I + i] = weight[((size_t)o * I + i) * taps + tp];
     const long px = (long)T * H * W;
     f16* d0 = up16(c, x0, px * C0); f16* d1 = C1 ? up16(c, x1, px * C1) : nullptr;
     f16* dW = up16(c, wp.data(), (long)wp.size()); f16* db = up16_opt(c, bias, O);
@@ -613,7 +614,7 @@ int ug_op_conv(ug_ctx* x, const float* x0, int C0, const float* x1, int C1, int 
     p.conv = 1; p.A0 = d0; p.A1 = d1; p.C0 = C0; p.C1 = C1; p.T = T; p.Hi = H; p.Wi = W; p.Ho = Ho; p.Wo = Wo;
     p.ups = ups; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l; p.kt = kt; p.ky = k; p.kx = k;
     p.M = T * Ho * Wo; p.N = O; p.K = I * taps; p.W = dW; p.ldw = p.K; p.bias = db; p.c0 = 1.f;
-    p.Out = dO; p.ldo = O; p.zero = c.zero; p.nb_inner = 1;
+    p.Out = dO; p.ldo = O; p.zero = c.zero; p.nb_inner = 1; p.kchunk = kch;
     { int cf, sp; gemm_plan(p, 1, &cf, &sp); p.cfg_p1 = cf + 1; p.splitk = sp; if (sp > 1) p.partial = c.ws.get<float>((long)sp * p.M * p.N); }
     launch_gemm(p, 1, c.stream);
     down16(c, dO, out, (long)T * Ho * Wo * O);

@@ -69,6 +69,8 @@ struct GemmP {
   // MX-fp8 dense path (launch_gemm_mx8): A0 / W point at OCP e4m3 bytes ([M][K] / [N][K], K % 128 == 0); sa / sw hold the e8m0 block
   // scales, four per dword (K blocks of 32 inside one 128-wide K step), K-step-major: sa[kstep * ld_sa + m], sw[kstep * ld_sw + n]
   const unsigned* sa; const unsigned* sw; long ld_sa, ld_sw;
+  int kchunk;            // im2col K order: 0 = [tap][channel] (weights [N][taps][C]); 1 = [64-channel chunk][tap][64] - all taps of a chunk are
+                         // consecutive K steps, so the activation rows a tile re-reads per tap are still in the XCD's L2 (needs (C0+C1) % 64 == 0)
   int group_m;           // tile walk: 0 / 1 = row-major, g > 1 = g M-tiles x all N tiles column by column (set by launch_gemm; see tile_coord)
 };
 void launch_gemm_mx8(const GemmP& p, hipStream_t s);   // dense only; C0 = lda and ldw in BYTES (= elements)
@@ -76,7 +78,8 @@ void launch_gemm_mx8(const GemmP& p, hipStream_t s);   // dense only; C0 = lda a
 void launch_quant_mx8(const f16* x, long ldx, long M, int K, unsigned char* q, unsigned* scales, long ld_s, hipStream_t s);
 void launch_gemm(const GemmP& p, int batch, hipStream_t s);
 void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out);   // heuristic used when cfg/splitk are 0
-void gemm_force(int cfg, int split);                                       // tuning aid: override the heuristic (-1 = off)
+void gemm_force(int cfg, int split);
+int gemm_knobs_get();                                       // tuning aid: override the heuristic (-1 = off)
 
 // Fused GEGLU feed-forward (kernels/ff_fused.hip): Out = c0 * (GEGLU(X W1^T + b1) W2^T + b2) + c1 R1 + c2 R2, all [M, C] row-major (ld = C);
 // W1 [8C][C] / b1 [8C] in the bound GEGLU row order (blocks of 16 rows = [8 value | 8 gate]), W2 [C][4C], C in {64,...,320}
@@ -155,6 +158,7 @@ void launch_cast_f16_f32(const f16* in, float* out, long n, hipStream_t s);
 void launch_permute_conv_w(const f16* in, f16* out, int O, int I, int taps, int Ipad, int Opad,
                            hipStream_t s);   // [O][I][taps] -> [Opad][taps][Ipad] (zero padded)
 void launch_upsample_phase_w(const f16* w9, f16* w4, int O, int I, int Ipad, hipStream_t s);   // [O][I][3][3] -> 4 x [O][2*2][Ipad]
+void launch_rechunk_conv_w(const f16* in, f16* out, long O, int taps, int Ipad, hipStream_t s);   // [O][taps][Ipad] -> [O][Ipad/64][taps][64]
 void launch_gather_rows(const f16* in, f16* out, const int* rowmap, int rows, int cols, hipStream_t s);
 void launch_copy2d(const f16* in, long ldi, f16* out, long ldo, long rows, int cols, hipStream_t s);
 void launch_fill_f16(f16* p, float v, long n, hipStream_t s);

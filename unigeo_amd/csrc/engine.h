@@ -32,7 +32,8 @@ struct Lin { const f16* w = nullptr; const f16* b = nullptr; int in = 0, out = 0
              // optional MX-fp8 copy of the weight (kernels/mx8.hip): e4m3 bytes [out][in] + e8m0 block scales [in/128][ld_sw8] dwords
              const unsigned char* w8 = nullptr; const unsigned* sw8 = nullptr; long ld_sw8 = 0; };
 struct Conv { const f16* w = nullptr; const f16* b = nullptr; int cin = 0, cinp = 0, cout = 0, kt = 1, ky = 1, kx = 1;
-              const f16* wphase = nullptr; };   // wphase: 4 x [cout][2*2][cinp] sub-pixel weights of a nearest-2x upsample conv
+              const f16* wphase = nullptr;     // wphase: 4 x [cout][2*2][cinp] sub-pixel weights of a nearest-2x upsample conv
+              int kchunk = 0; };               // 1: w / wphase are in the chunk-major K order [cout][cinp/64][taps][64] (GemmP::kchunk)
 struct Norm { const f16* g = nullptr; const f16* b = nullptr; int c = 0; float eps = 1e-5f; };
 
 struct Res2D { Norm n1, n2; Conv c1, c2, sc; Lin temb; bool has_sc = false, has_temb = false; int tidx = -1; };

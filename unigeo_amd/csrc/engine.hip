@@ -167,7 +167,7 @@ static void conv(Ctx& c, const f16* x0, int C0, const f16* x1, int C1, int T, in
       p.kt = 1; p.ky = 2; p.kx = 2; p.Ho = Hi; p.Wo = Wi;
       p.M = T * Hi * Wi; p.N = cv.cout; p.K = cv.cinp * 4;
       p.W = cv.wphase + (long)ph * cv.cout * 4 * cv.cinp; p.ldw = p.K; p.bias = cv.b; p.bias2 = e.bias2;
-      p.c0 = e.c0; p.act = e.act; p.flags = e.flags; p.Out = out; p.ldo = ldo ? ldo : cv.cout; p.up_phase = 1 + ph;
+      p.c0 = e.c0; p.act = e.act; p.flags = e.flags; p.Out = out; p.ldo = ldo ? ldo : cv.cout; p.up_phase = 1 + ph; p.kchunk = cv.kchunk;
       UG_REQUIRE(!e.R1 && !e.R2, "sub-pixel upsample conv does not take residuals");
       run_gemm(c, p, 1, "gemm_conv_up2x2");
     }
@@ -182,7 +182,7 @@ static void conv(Ctx& c, const f16* x0, int C0, const f16* x1, int C1, int T, in
   p.W = cv.w; p.ldw = p.K; p.bias = cv.b; p.bias2 = e.bias2;
   p.R1 = e.R1; p.ldr1 = e.ldr1 ? e.ldr1 : cv.cout; p.c1 = e.c1;
   p.R2 = e.R2; p.ldr2 = e.ldr2 ? e.ldr2 : cv.cout; p.c2 = e.c2; p.c0 = e.c0; p.act = e.act; p.flags = e.flags;
-  p.Out = out; p.ldo = ldo ? ldo : cv.cout;
+  p.Out = out; p.ldo = ldo ? ldo : cv.cout; p.kchunk = cv.kchunk;
   run_gemm(c, p, 1, cv.kt > 1 ? "gemm_tconv" : (cv.ky > 1 ? "gemm_conv3x3" : "gemm_conv1x1"));
 }
 
@@ -355,16 +355,36 @@ static Conv bind_conv(Ctx& c, const std::string& p, int cin, int cout, int kt, i
     cv.wphase = w4;
   }
   cv.b = bias ? persist_f16(c, raw_get(c, p + ".bias", {cout})) : nullptr;
+  // chunk-major K order for every multi-tap conv whose channels come in whole 64-blocks (GemmP::kchunk): taps of a chunk are consecutive
+  if (taps > 1 && cv.cinp % 64 == 0 && !getenv("UG_NO_KCHUNK")) {
+    const size_t mk3 = c.persist.mark();
+    f16* tmp = c.persist.get<f16>((long)cout * taps * cv.cinp);
+    UG_CHECK(hipMemcpyAsync(tmp, w, (size_t)cout * taps * cv.cinp * 2, hipMemcpyDeviceToDevice, c.stream));
+    launch_rechunk_conv_w(tmp, w, cout, taps, cv.cinp, c.stream);
+    if (cv.wphase) {
+      f16* t4 = c.persist.get<f16>((long)4 * cout * 4 * cv.cinp);
+      UG_CHECK(hipMemcpyAsync(t4, cv.wphase, (size_t)4 * cout * 4 * cv.cinp * 2, hipMemcpyDeviceToDevice, c.stream));
+      launch_rechunk_conv_w(t4, (f16*)cv.wphase, (long)4 * cout, 4, cv.cinp, c.stream);
+    }
+    UG_CHECK(hipStreamSynchronize(c.stream));
+    c.persist.release(mk3);
+    cv.kchunk = 1;
+  }
   return cv;
 }
 
 // K-doubled copies for fp16 hi/lo-pair activations (kernels/wide.hip): [O][taps][Cinp] -> [O][taps][Cinp | Cinp], [N][K] -> [N][K | K]
 static Conv dup_conv(Ctx& c, const Conv& cv) {
   Conv d = cv; d.wphase = nullptr;
-  const long rows = (long)cv.cout * cv.kt * cv.ky * cv.kx;
-  f16* w = c.persist.get<f16>(rows * 2 * cv.cinp);
-  launch_copy2d(cv.w, cv.cinp, w, 2 * cv.cinp, rows, cv.cinp, c.stream);
-  launch_copy2d(cv.w, cv.cinp, w + cv.cinp, 2 * cv.cinp, rows, cv.cinp, c.stream);
+  const int taps = cv.kt * cv.ky * cv.kx;
+  // tap-major rows are [taps][Cinp] -> [taps][Cinp | Cinp]; chunk-major rows are [chunks][taps][64] -> the lo half is simply a second
+  // run of chunks, i.e. the whole row twice (a doubled, 64-divisible channel count stays chunk-major)
+  const long rows = cv.kchunk ? (long)cv.cout : (long)cv.cout * taps;
+  const long cols = cv.kchunk ? (long)taps * cv.cinp : cv.cinp;
+  f16* w = c.persist.get<f16>(rows * 2 * cols);
+  launch_copy2d(cv.w, cols, w, 2 * cols, rows, (int)cols, c.stream);
+  launch_copy2d(cv.w, cols, w + cols, 2 * cols, rows, (int)cols, c.stream);
+  if (!cv.kchunk && taps > 1 && (2 * cv.cinp) % 64 == 0) d.kchunk = 0;   // stays tap-major (conv() passes d.kchunk)
   d.w = w; d.cin = 2 * cv.cinp; d.cinp = 2 * cv.cinp;
   return d;
 }

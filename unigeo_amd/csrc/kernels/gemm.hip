@@ -393,8 +393,13 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
     int it = 0, iy = 0, ix = 0, cb = 0;
     if (CONV && UNI) {  // whole K tile sits inside one tap
       if (ld_ks == 0) {   // first K tile of a tile: decode once (split-K may start mid-way)
-        const int tap = kt0 / Cin;
+        int tap = kt0 / Cin;
         u_cb = kt0 - tap * Cin;
+        if (p.kchunk) {   // chunk-major K: step q = kt0 / BK is (channel chunk q / taps, tap q % taps)
+          const int q = kt0 / BK, ntap = p.kt * p.ky * p.kx;
+          const int chk = q / ntap;
+          tap = q - chk * ntap; u_cb = chk * BK;
+        }
         u_it = tap / (p.ky * p.kx);
         const int r2 = tap - u_it * (p.ky * p.kx);
         u_iy = r2 / p.kx; u_ix = r2 - u_iy * p.kx;
@@ -425,8 +430,12 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
           __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (wave * AI + j) * RPI * BK), 16, 0, 0);
         }
       }
-      u_cb += BK;
-      if (u_cb >= Cin) { u_cb = 0; if (++u_ix == p.kx) { u_ix = 0; if (++u_iy == p.ky) { u_iy = 0; ++u_it; } } }
+      if (p.kchunk) {   // next tap of the same channel chunk; after the last tap the next chunk
+        if (++u_ix == p.kx) { u_ix = 0; if (++u_iy == p.ky) { u_iy = 0; if (++u_it == p.kt) { u_it = 0; u_cb += BK; } } }
+      } else {
+        u_cb += BK;
+        if (u_cb >= Cin) { u_cb = 0; if (++u_ix == p.kx) { u_ix = 0; if (++u_iy == p.ky) { u_iy = 0; ++u_it; } } }
+      }
     }
     if (BUFA && !CONV) {
 #pragma unroll
@@ -713,8 +722,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ldr_kernel(const GemmP p) {
       setup_tile(wslot + ld_ti * nwg);
       if (CONV) {
         const int kt0 = kt_lo * BK;
-        const int tap = kt0 / Cin;
+        int tap = kt0 / Cin;
         u_cb = kt0 - tap * Cin;
+        if (p.kchunk) {   // chunk-major K: step q = kt0 / BK is (channel chunk q / taps, tap q % taps)
+          const int q = kt0 / BK, ntap = p.kt * p.ky * p.kx;
+          const int chk = q / ntap;
+          tap = q - chk * ntap; u_cb = chk * BK;
+        }
         u_it = tap / (p.ky * p.kx);
         const int r2 = tap - u_it * (p.ky * p.kx);
         u_iy = r2 / p.kx; u_ix = r2 - u_iy * p.kx;
@@ -737,8 +751,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ldr_kernel(const GemmP p) {
         const unsigned voff = ((a_st[l] >> tapbit) & 1u) ? off : SENT;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(As + rg * 8 * BK), 16, (int)voff, soff, 0, 0);
       }
-      u_cb += BK;
-      if (u_cb >= Cin) { u_cb = 0; if (++u_ix == p.kx) { u_ix = 0; if (++u_iy == p.ky) { u_iy = 0; ++u_it; } } }
+      if (p.kchunk) {   // next tap of the same channel chunk; after the last tap the next chunk
+        if (++u_ix == p.kx) { u_ix = 0; if (++u_iy == p.ky) { u_iy = 0; if (++u_it == p.kt) { u_it = 0; u_cb += BK; } } }
+      } else {
+        u_cb += BK;
+        if (u_cb >= Cin) { u_cb = 0; if (++u_ix == p.kx) { u_ix = 0; if (++u_iy == p.ky) { u_iy = 0; ++u_it; } } }
+      }
     } else {
 #pragma unroll
       for (int l = 0; l < LA; ++l) {
@@ -955,8 +973,13 @@ __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(const GemmP p) {
         }
         if (CONV) {
           const int kt0 = kt_lo * BK;
-          const int tap = kt0 / Cin;
+          int tap = kt0 / Cin;
           u_cb = kt0 - tap * Cin;
+          if (p.kchunk) {   // chunk-major K: step q = kt0 / BK is (channel chunk q / taps, tap q % taps)
+            const int q = kt0 / BK, ntap = p.kt * p.ky * p.kx;
+            const int chk = q / ntap;
+            tap = q - chk * ntap; u_cb = chk * BK;
+          }
           u_it = tap / (p.ky * p.kx);
           const int r2 = tap - u_it * (p.ky * p.kx);
           u_iy = r2 / p.kx; u_ix = r2 - u_iy * p.kx;
@@ -978,8 +1001,12 @@ __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(const GemmP p) {
           const unsigned voff = ((a_st[l] >> tapbit) & 1u) ? off : SENT;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(As + (pw * LA + l) * 8 * BK), 16, (int)voff, soff, 0, 0);
         }
-        u_cb += BK;
-        if (u_cb >= Cin) { u_cb = 0; if (++u_ix == p.kx) { u_ix = 0; if (++u_iy == p.ky) { u_iy = 0; ++u_it; } } }
+        if (p.kchunk) {   // next tap of the same channel chunk; after the last tap the next chunk
+          if (++u_ix == p.kx) { u_ix = 0; if (++u_iy == p.ky) { u_iy = 0; if (++u_it == p.kt) { u_it = 0; u_cb += BK; } } }
+        } else {
+          u_cb += BK;
+          if (u_cb >= Cin) { u_cb = 0; if (++u_ix == p.kx) { u_ix = 0; if (++u_iy == p.ky) { u_iy = 0; ++u_it; } } }
+        }
       } else {
 #pragma unroll
         for (int l = 0; l < LA; ++l)
@@ -1363,7 +1390,7 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
 // Tile-walk grouping for dense layers whose weights do not fit the per-XCD L2 (tile_coord): the ~P tiles an XCD processes at a time
 // should touch as few operand panels as possible: a x b = P with a * BM ~ b * BN.
 static int pick_group_m(const GemmP& p, int cfg, int batch, int split) {
-  if ((p.conv && (g_knobs & 64)) || batch > 1 || split > 1 || (g_knobs & 32)) return 1;   // knobs: 32 = row-major walk everywhere, 64 = row-major for im2col (A/B)
+  if ((p.conv && (g_knobs & 64)) || batch > 1 || (g_knobs & 32)) return 1;   // knobs: 32 = row-major walk everywhere, 64 = row-major for im2col (A/B)
   if ((double)p.N * p.K * 2.0 <= 3.0 * (1 << 20)) return 1;          // weights stay L2 resident: share the activation panel instead
   int bm = 256, bn = 128, percu = 1;
   switch (cfg) {

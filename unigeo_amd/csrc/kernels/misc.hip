@@ -34,6 +34,21 @@ void launch_permute_conv_w(const f16* in, f16* out, int O, int I, int taps, int 
   hipLaunchKernelGGL(k_permute_conv_w, gs_grid((long)Opad * taps * Ipad), dim3(256), 0, s, in, out, O, I, taps, Ipad, Opad);
 }
 
+// [O][taps][Ipad] -> [O][Ipad/64][taps][64]: the chunk-major K order of the implicit-GEMM kernels (GemmP::kchunk)
+__global__ void k_rechunk_conv_w(const f16* in, f16* out, long O, int taps, int Ipad) {
+  const long n = O * taps * Ipad;
+  GS_LOOP(idx, n) {
+    const int c = idx % 64;
+    const int tp = (idx / 64) % taps;
+    const int chk = (idx / (64L * taps)) % (Ipad / 64);
+    const long o = idx / ((long)Ipad * taps);
+    out[idx] = in[(o * taps + tp) * Ipad + chk * 64 + c];
+  }
+}
+void launch_rechunk_conv_w(const f16* in, f16* out, long O, int taps, int Ipad, hipStream_t s) {
+  hipLaunchKernelGGL(k_rechunk_conv_w, gs_grid(O * taps * Ipad), dim3(256), 0, s, in, out, O, taps, Ipad);
+}
+
 // nearest-2x upsample followed by a zero-padded 3x3 conv == four 2x2 convs on the source grid, one per output parity
 // (a,b): rows 2y-1,2y,2y+1 of the upsampled image are source rows y-1,y,y (a=0) or y,y,y+1 (a=1), so the 3 taps
 // collapse to 2 with weights {w0, w1+w2} or {w0+w1, w2}; same along x.  Sums are formed in fp32 and rounded once.
