@@ -602,7 +602,7 @@ int ug_op_conv(ug_ctx* x, const float* x0, int C0, const float* x1, int C1, int 
     Ctx& c = x->c; Scope sc(c);
     const int I = C0 + C1, taps = kt * k * k;
     std::vector<float> wp((size_t)O * taps * I);
-    const bool kch = (I % 64 == 0) && taps > 1 && !getenv("UG_NO_KCHUNK");     // the engine's chunk-major K order (GemmP::kchunk)
+    const bool kch = (I % 64 == 0) && taps > 1 && !getenv("UG_NO_KCHUNK");     // the engine's chunk-major K order (GemmP::kchunk); UG_NO_KCHUNK: tap-major weights -> general path
     for (int o = 0; o < O; ++o) for (int i = 0; i < I; ++i) for (int tp = 0; tp < taps; ++tp)
       wp[kch ? (((size_t)o * (I / 64) + i / 64) * taps + tp) * 64 + i % 64 : ((size_t)o * taps + tp) * I + i] = weight[((size_t)o * I + i) * taps + tp];
     const long px = (long)T * H * W;

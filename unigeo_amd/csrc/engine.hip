@@ -356,7 +356,7 @@ static Conv bind_conv(Ctx& c, const std::string& p, int cin, int cout, int kt, i
   }
   cv.b = bias ? persist_f16(c, raw_get(c, p + ".bias", {cout})) : nullptr;
   // chunk-major K order for every multi-tap conv whose channels come in whole 64-blocks (GemmP::kchunk): taps of a chunk are consecutive
-  if (taps > 1 && cv.cinp % 64 == 0 && !getenv("UG_NO_KCHUNK")) {
+  if (taps > 1 && cv.cinp % 64 == 0) {
     const size_t mk3 = c.persist.mark();
     f16* tmp = c.persist.get<f16>((long)cout * taps * cv.cinp);
     UG_CHECK(hipMemcpyAsync(tmp, w, (size_t)cout * taps * cv.cinp * 2, hipMemcpyDeviceToDevice, c.stream));
@@ -384,7 +384,8 @@ static Conv dup_conv(Ctx& c, const Conv& cv) {
   f16* w = c.persist.get<f16>(rows * 2 * cols);
   launch_copy2d(cv.w, cols, w, 2 * cols, rows, (int)cols, c.stream);
   launch_copy2d(cv.w, cols, w + cols, 2 * cols, rows, (int)cols, c.stream);
-  if (!cv.kchunk && taps > 1 && (2 * cv.cinp) % 64 == 0) d.kchunk = 0;   // stays tap-major (conv() passes d.kchunk)
+  // a tap-major base (Cinp % 64 != 0) whose doubled channel count is a multiple of 64 keeps the tap-major layout: the kernels then take
+  // the general (non single-tap) path unless it is one chunk, where both orders coincide
   d.w = w; d.cin = 2 * cv.cinp; d.cinp = 2 * cv.cinp;
   return d;
 }

@@ -393,13 +393,11 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
     int it = 0, iy = 0, ix = 0, cb = 0;
     if (CONV && UNI) {  // whole K tile sits inside one tap
       if (ld_ks == 0) {   // first K tile of a tile: decode once (split-K may start mid-way)
-        int tap = kt0 / Cin;
-        u_cb = kt0 - tap * Cin;
-        if (p.kchunk) {   // chunk-major K: step q = kt0 / BK is (channel chunk q / taps, tap q % taps)
-          const int q = kt0 / BK, ntap = p.kt * p.ky * p.kx;
-          const int chk = q / ntap;
-          tap = q - chk * ntap; u_cb = chk * BK;
-        }
+        // chunk-major K: step q = kt0 / BK is (channel chunk q / taps, tap q % taps)
+        const int q = kt0 / BK, ntap = p.kt * p.ky * p.kx;
+        const int chk = q / ntap;
+        const int tap = q - chk * ntap;
+        u_cb = chk * BK;
         u_it = tap / (p.ky * p.kx);
         const int r2 = tap - u_it * (p.ky * p.kx);
         u_iy = r2 / p.kx; u_ix = r2 - u_iy * p.kx;
@@ -430,12 +428,8 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
           __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (wave * AI + j) * RPI * BK), 16, 0, 0);
         }
       }
-      if (p.kchunk) {   // next tap of the same channel chunk; after the last tap the next chunk
-        if (++u_ix == p.kx) { u_ix = 0; if (++u_iy == p.ky) { u_iy = 0; if (++u_it == p.kt) { u_it = 0; u_cb += BK; } } }
-      } else {
-        u_cb += BK;
-        if (u_cb >= Cin) { u_cb = 0; if (++u_ix == p.kx) { u_ix = 0; if (++u_iy == p.ky) { u_iy = 0; ++u_it; } } }
-      }
+      // chunk-major K order (the only one the single-tap-per-K-tile paths take): next tap of the same 64-channel chunk, then the next chunk
+      if (++u_ix == p.kx) { u_ix = 0; if (++u_iy == p.ky) { u_iy = 0; if (++u_it == p.kt) { u_it = 0; u_cb += BK; } } }
     }
     if (BUFA && !CONV) {
 #pragma unroll
@@ -455,8 +449,9 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
           if (UNI) {
             c = cb + a_lc[j] * 8;
           } else {
-            const int tap = k / Cin;
+            int tap = k / Cin;
             c = k - tap * Cin;
+            if (p.kchunk) { const int q = k / 64, ntap = p.kt * p.ky * p.kx, chk = q / ntap; tap = q - chk * ntap; c = chk * 64 + (k & 63); }
             it = tap / (p.ky * p.kx);
             const int r2 = tap - it * (p.ky * p.kx);
             iy = r2 / p.kx; ix = r2 - iy * p.kx;
@@ -722,13 +717,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ldr_kernel(const GemmP p) {
       setup_tile(wslot + ld_ti * nwg);
       if (CONV) {
         const int kt0 = kt_lo * BK;
-        int tap = kt0 / Cin;
-        u_cb = kt0 - tap * Cin;
-        if (p.kchunk) {   // chunk-major K: step q = kt0 / BK is (channel chunk q / taps, tap q % taps)
-          const int q = kt0 / BK, ntap = p.kt * p.ky * p.kx;
-          const int chk = q / ntap;
-          tap = q - chk * ntap; u_cb = chk * BK;
-        }
+        // chunk-major K: step q = kt0 / BK is (channel chunk q / taps, tap q % taps)
+        const int q = kt0 / BK, ntap = p.kt * p.ky * p.kx;
+        const int chk = q / ntap;
+        const int tap = q - chk * ntap;
+        u_cb = chk * BK;
         u_it = tap / (p.ky * p.kx);
         const int r2 = tap - u_it * (p.ky * p.kx);
         u_iy = r2 / p.kx; u_ix = r2 - u_iy * p.kx;
@@ -751,12 +744,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ldr_kernel(const GemmP p) {
         const unsigned voff = ((a_st[l] >> tapbit) & 1u) ? off : SENT;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(As + rg * 8 * BK), 16, (int)voff, soff, 0, 0);
       }
-      if (p.kchunk) {   // next tap of the same channel chunk; after the last tap the next chunk
-        if (++u_ix == p.kx) { u_ix = 0; if (++u_iy == p.ky) { u_iy = 0; if (++u_it == p.kt) { u_it = 0; u_cb += BK; } } }
-      } else {
-        u_cb += BK;
-        if (u_cb >= Cin) { u_cb = 0; if (++u_ix == p.kx) { u_ix = 0; if (++u_iy == p.ky) { u_iy = 0; ++u_it; } } }
-      }
+      // chunk-major K order (the only one the single-tap-per-K-tile paths take): next tap of the same 64-channel chunk, then the next chunk
+      if (++u_ix == p.kx) { u_ix = 0; if (++u_iy == p.ky) { u_iy = 0; if (++u_it == p.kt) { u_it = 0; u_cb += BK; } } }
     } else {
 #pragma unroll
       for (int l = 0; l < LA; ++l) {
@@ -854,7 +843,8 @@ static bool gemm_can_bufa(const GemmP& p, int BK, bool packed) {
   const long lim = (1L << 31) - 64;
   if ((long)p.N * p.ldw * 2 >= lim) return false;
   if (p.conv) {
-    const bool uni = ((p.C0 + p.C1) % BK) == 0 && (p.C0 % BK) == 0 && p.kt * p.ky * p.kx <= (packed ? 9 : 32);
+    const bool kc_ok = p.kchunk || p.kt * p.ky * p.kx == 1 || (p.C0 + p.C1) == BK;
+    const bool uni = kc_ok && ((p.C0 + p.C1) % BK) == 0 && (p.C0 % BK) == 0 && p.kt * p.ky * p.kx <= (packed ? 9 : 32);
     const long px = (long)p.T * p.Hi * p.Wi + ((long)(p.kt >> 1) * p.Hi + p.pad_t) * p.Wi + p.pad_l + 1;
     return uni && p.ups == 1 && px * p.C0 * 2 < lim && px * p.C1 * 2 < lim && (!packed || px < (1L << 23));
   }
@@ -973,13 +963,11 @@ __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(const GemmP p) {
         }
         if (CONV) {
           const int kt0 = kt_lo * BK;
-          int tap = kt0 / Cin;
-          u_cb = kt0 - tap * Cin;
-          if (p.kchunk) {   // chunk-major K: step q = kt0 / BK is (channel chunk q / taps, tap q % taps)
-            const int q = kt0 / BK, ntap = p.kt * p.ky * p.kx;
-            const int chk = q / ntap;
-            tap = q - chk * ntap; u_cb = chk * BK;
-          }
+          // chunk-major K: step q = kt0 / BK is (channel chunk q / taps, tap q % taps)
+          const int q = kt0 / BK, ntap = p.kt * p.ky * p.kx;
+          const int chk = q / ntap;
+          const int tap = q - chk * ntap;
+          u_cb = chk * BK;
           u_it = tap / (p.ky * p.kx);
           const int r2 = tap - u_it * (p.ky * p.kx);
           u_iy = r2 / p.kx; u_ix = r2 - u_iy * p.kx;
@@ -1001,12 +989,8 @@ __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(const GemmP p) {
           const unsigned voff = ((a_st[l] >> tapbit) & 1u) ? off : SENT;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(As + (pw * LA + l) * 8 * BK), 16, (int)voff, soff, 0, 0);
         }
-        if (p.kchunk) {   // next tap of the same channel chunk; after the last tap the next chunk
-          if (++u_ix == p.kx) { u_ix = 0; if (++u_iy == p.ky) { u_iy = 0; if (++u_it == p.kt) { u_it = 0; u_cb += BK; } } }
-        } else {
-          u_cb += BK;
-          if (u_cb >= Cin) { u_cb = 0; if (++u_ix == p.kx) { u_ix = 0; if (++u_iy == p.ky) { u_iy = 0; ++u_it; } } }
-        }
+        // chunk-major K order (the only one the single-tap-per-K-tile paths take): next tap of the same 64-channel chunk, then the next chunk
+        if (++u_ix == p.kx) { u_ix = 0; if (++u_iy == p.ky) { u_iy = 0; if (++u_it == p.kt) { u_it = 0; u_cb += BK; } } }
       } else {
 #pragma unroll
         for (int l = 0; l < LA; ++l)
@@ -1234,7 +1218,9 @@ static void launch_mode(const GemmP& p, int batch, hipStream_t s) {
   const long lim = (1L << 31) - 64;   // buffer addressing: every byte offset must stay below num_records
   const bool bufw = (long)p.N * p.ldw * 2 < lim && !(gemm_knobs_get() & 4);
   if (p.conv) {
-    const bool uni = ((p.C0 + p.C1) % BK) == 0 && (p.C0 % BK) == 0 && p.kt * p.ky * p.kx <= 32;
+    // the single-tap-per-K-tile paths walk K chunk-major: the weights must be laid out that way (trivially true for 1 tap / 1 chunk)
+    const bool kc_ok = p.kchunk || p.kt * p.ky * p.kx == 1 || (p.C0 + p.C1) == BK;
+    const bool uni = kc_ok && ((p.C0 + p.C1) % BK) == 0 && (p.C0 % BK) == 0 && p.kt * p.ky * p.kx <= 32;
     const long px = (long)p.T * p.Hi * p.Wi + ((long)(p.kt >> 1) * p.Hi + p.pad_t) * p.Wi + p.pad_l + 1;
     const bool bufa = bufw && uni && p.ups == 1 && px * p.C0 * 2 < lim && px * p.C1 * 2 < lim;
     if (uni && bufa) launch_t<BM, BN, BK, NST, WMW, WNW, true, true, true>(p, batch, s);
