@@ -82,9 +82,10 @@ std::string prof_end(Ctx& c) {
 struct Epi {
   const f16* bias2 = nullptr; const f16* R1 = nullptr; long ldr1 = 0; float c1 = 1.f;
   const f16* R2 = nullptr; long ldr2 = 0; float c2 = 1.f; float c0 = 1.f; int act = 0; int flags = 0;
+  float alg = 1.f;   // algorithmic / executed FLOPs of this launch (0.5 for the K-doubled hi/lo-pair GEMMs of the float32-grade encoder)
 };
 
-static void run_gemm(Ctx& c, GemmP p, int batch, const char* tag) {
+static void run_gemm(Ctx& c, GemmP p, int batch, const char* tag, float alg = 1.f) {
   p.zero = c.zero;
   if (p.nb_inner < 1) p.nb_inner = 1;
   char nm[128];
@@ -102,7 +103,7 @@ static void run_gemm(Ctx& c, GemmP p, int batch, const char* tag) {
     const double a_el = p.conv ? (double)p.T * p.Hi * p.Wi * (p.C0 + p.C1) : (double)p.M * p.K;
     const double bytes = 2.0 * batch * (a_el + (double)p.N * p.K + (double)p.M * nout * ((p.flags & UG_F_OUT_F32) ? 2 : 1) +
                                         (p.R1 ? (double)p.M * nout : 0.0) + (p.R2 ? (double)p.M * nout : 0.0));
-    ProfScope ps(c, nm, 2.0 * p.M * p.N * (double)p.K * batch * (p.up_phase ? 2.25 : 1.0), bytes);
+    ProfScope ps(c, nm, 2.0 * p.M * p.N * (double)p.K * batch * (p.up_phase ? 2.25 : 1.0) * alg, bytes);
     launch_gemm(p, batch, c.stream);
   }
   c.ws.release(mk);
@@ -151,7 +152,7 @@ static void linear(Ctx& c, const f16* A, long M, const Lin& l, f16* out, const E
   p.Out = out; p.ldo = ldo ? ldo : nout;
   if (p.R1 && !p.ldr1) p.ldr1 = nout;
   if (p.R2 && !p.ldr2) p.ldr2 = nout;
-  run_gemm(c, p, 1, "gemm_linear");
+  run_gemm(c, p, 1, "gemm_linear", e.alg);
 }
 
 // implicit-GEMM convolution over channels-last sources
@@ -183,7 +184,7 @@ static void conv(Ctx& c, const f16* x0, int C0, const f16* x1, int C1, int T, in
   p.R1 = e.R1; p.ldr1 = e.ldr1 ? e.ldr1 : cv.cout; p.c1 = e.c1;
   p.R2 = e.R2; p.ldr2 = e.ldr2 ? e.ldr2 : cv.cout; p.c2 = e.c2; p.c0 = e.c0; p.act = e.act; p.flags = e.flags;
   p.Out = out; p.ldo = ldo ? ldo : cv.cout; p.kchunk = cv.kchunk;
-  run_gemm(c, p, 1, cv.kt > 1 ? "gemm_tconv" : (cv.ky > 1 ? "gemm_conv3x3" : "gemm_conv1x1"));
+  run_gemm(c, p, 1, cv.kt > 1 ? "gemm_tconv" : (cv.ky > 1 ? "gemm_conv3x3" : "gemm_conv1x1"), e.alg);
 }
 
 static void groupnorm(Ctx& c, const f16* x0, int C0, const f16* x1, int C1, int T, int HW, int G, const Norm& n,
@@ -1008,7 +1009,7 @@ static void add_f32(Ctx& c, const float* a, const float* b, float* y, long n) {
 }
 // conv over a pair tensor [M, 2C] with K-doubled weights -> fp32 [M, cout]
 static void conv_w(Ctx& c, const f16* xpair, int T, int Hi, int Wi, const Conv& cv, int stride, int pad_t, int pad_l, float* out) {
-  Epi e; e.flags = UG_F_OUT_F32;
+  Epi e; e.flags = UG_F_OUT_F32; e.alg = 0.5f;
   conv(c, xpair, cv.cinp, nullptr, 0, T, Hi, Wi, cv, stride, pad_t, pad_l, 1, (f16*)out, e);
 }
 static void res2d_wide(Ctx& c, const Res2D& r, const float* x, int cin, int T, int h, int w, int G, float* out) {
@@ -1036,7 +1037,7 @@ static void vattn_wide(Ctx& c, const VAttn& at, const float* x, int T, int hw, i
   f16* xn = c.ws.get<f16>(M * 2 * C);
   gn32(c, x, T, hw, G, at.gn, 0, xn);
   float* qkv = c.ws.get<float>(M * 3 * C);
-  { Epi e; e.flags = UG_F_OUT_F32; linear(c, xn, M, at.qkv, (f16*)qkv, e); }
+  { Epi e; e.flags = UG_F_OUT_F32; e.alg = 0.5f; linear(c, xn, M, at.qkv, (f16*)qkv, e); }
   f16* Aq = c.ws.get<f16>(M * 3 * C); f16* Bk = c.ws.get<f16>(M * 3 * C);
   launch_qk_terms(qkv, Aq, Bk, M, C, c.stream);
   f16* Vt = c.ws.get<f16>((long)T * C * 3 * Spad);
@@ -1046,7 +1047,7 @@ static void vattn_wide(Ctx& c, const VAttn& at, const float* x, int T, int hw, i
   p.A0 = Aq; p.C0 = 3 * C; p.M = S; p.N = S; p.K = 3 * C; p.W = Bk; p.ldw = 3 * C;
   p.c0 = 1.0f / sqrtf((float)C); p.Out = sc; p.ldo = Spad; p.flags = UG_F_OUT_F32;
   p.nb_inner = 1; p.sA_o = (long)S * 3 * C; p.sW_o = (long)S * 3 * C; p.sO_o = (long)S * Spad;
-  run_gemm(c, p, T, "gemm_attn_qk");
+  run_gemm(c, p, T, "gemm_attn_qk", 1.f / 3.f);
   f16* P = c.ws.get<f16>((long)T * S * 3 * Spad);
   {
     ProfScope ps(c, "softmax_rows", 0, (double)T * S * Spad * 10.0);
@@ -1057,10 +1058,10 @@ static void vattn_wide(Ctx& c, const VAttn& at, const float* x, int T, int hw, i
   q.A0 = P; q.C0 = 3 * Spad; q.M = S; q.N = C; q.K = 3 * Spad; q.W = Vt; q.ldw = 3 * Spad; q.c0 = 1.f;
   q.Out = ao; q.ldo = C; q.flags = UG_F_OUT_F32; q.nb_inner = 1;
   q.sA_o = (long)S * 3 * Spad; q.sW_o = (long)C * 3 * Spad; q.sO_o = (long)S * C;
-  run_gemm(c, q, T, "gemm_attn_pv");
+  run_gemm(c, q, T, "gemm_attn_pv", 1.f / 3.f);
   split_pair(c, ao, xn, M, C);
   float* o = c.ws.get<float>(M * C);
-  { Epi e; e.flags = UG_F_OUT_F32; linear(c, xn, M, at.out, (f16*)o, e); }
+  { Epi e; e.flags = UG_F_OUT_F32; e.alg = 0.5f; linear(c, xn, M, at.out, (f16*)o, e); }
   add_f32(c, o, x, out, M * C);
   c.ws.release(mk);
 }
