@@ -61,6 +61,13 @@ def test_fp8_unet_error_vs_fp16_path_and_oracle():
         eng.set_fp8_linears(True)
         y8 = eng.unet_forward(x, ts, emb)
         y8b = eng.unet_forward(x, ts, emb)
+        import os
+        os.environ["UG_NO_LNQ"] = "1"                     # LayerNorm -> fp16 -> separate quantiser pass instead of the fused MX-fp8 output
+        try:
+            y8c = eng.unet_forward(x, ts, emb)
+        finally:
+            del os.environ["UG_NO_LNQ"]
+        assert np.array_equal(y8, y8c)                    # the fused quantisation is bit-identical to the two-pass one
         eng.set_fp8_linears(False)
         assert np.array_equal(y8, y8b) and not np.array_equal(y8, y16)                 # deterministic, and really a different path
         unet = oracle_unet(u, su)

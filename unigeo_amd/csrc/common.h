@@ -113,6 +113,8 @@ struct LayerNormP {
   const f16* X; f16* Y; int M, C; float eps;
   const f16* gamma; const f16* beta;
   const f16* addvec; int rows_per_vec; f16* Xout;   // optional
+  // optional MX-fp8 output INSTEAD of Y (fp8 linear path): e4m3 bytes [M][C] + e8m0 block scales, layout of launch_quant_mx8 (C % 128 == 0)
+  unsigned char* Y8; unsigned* S8; long ld_s8;
 };
 void launch_layernorm(const LayerNormP& p, hipStream_t s);
 

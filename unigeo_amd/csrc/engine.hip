@@ -82,6 +82,7 @@ std::string prof_end(Ctx& c) {
 struct Epi {
   const f16* bias2 = nullptr; const f16* R1 = nullptr; long ldr1 = 0; float c1 = 1.f;
   const f16* R2 = nullptr; long ldr2 = 0; float c2 = 1.f; float c0 = 1.f; int act = 0; int flags = 0;
+  const unsigned char* a8 = nullptr; const unsigned* sa8 = nullptr; long ld_sa8 = 0;   // A already in MX-fp8 (written by the producing LayerNorm)
   float alg = 1.f;   // algorithmic / executed FLOPs of this launch (0.5 for the K-doubled hi/lo-pair GEMMs of the float32-grade encoder)
 };
 
@@ -118,15 +119,20 @@ static void linear(Ctx& c, const f16* A, long M, const Lin& l, f16* out, const E
     // MX-fp8 path: quantise the activation rows (32-element blocks, e8m0 scales), then the same persistent GEMM on e4m3 operands
     const size_t mk = c.ws.mark();
     const int K = l.in;
-    unsigned char* a8 = (unsigned char*)c.ws.alloc((size_t)M * K);
-    const long ld_sa = pad256(M);
-    unsigned* sa = (unsigned*)c.ws.alloc((size_t)(K / 128) * ld_sa * 4);
+    const unsigned char* a8 = e.a8; const unsigned* sa = e.sa8; long ld_sa = e.ld_sa8;
+    unsigned char* a8w = nullptr; unsigned* saw = nullptr;
+    if (!a8) {
+      a8w = (unsigned char*)c.ws.alloc((size_t)M * K);
+      ld_sa = pad256(M);
+      saw = (unsigned*)c.ws.alloc((size_t)(K / 128) * ld_sa * 4);
+      a8 = a8w; sa = saw;
+    }
     char nmq[96], nmg[96];
     if (c.prof_on && c.prof_shapes) { snprintf(nmq, sizeof(nmq), "quant_mx8:%ldx%d", M, K); snprintf(nmg, sizeof(nmg), "gemm_linear_mx8:%ldx%dx%d", M, l.out, K); }
     else { snprintf(nmq, sizeof(nmq), "quant_mx8"); snprintf(nmg, sizeof(nmg), "gemm_linear_mx8"); }
-    {
+    if (a8w) {
       ProfScope ps(c, nmq, 0, (double)M * K * 3.0);
-      launch_quant_mx8(A, lda ? lda : K, M, K, a8, sa, ld_sa, c.stream);
+      launch_quant_mx8(A, lda ? lda : K, M, K, a8w, saw, ld_sa, c.stream);
     }
     p.A0 = (const f16*)a8; p.C0 = K; p.M = (int)M; p.N = l.out; p.K = K;
     p.W = (const f16*)l.w8; p.ldw = K; p.bias = l.b; p.bias2 = e.bias2;
@@ -205,11 +211,19 @@ static void groupnorm(Ctx& c, const f16* x0, int C0, const f16* x1, int C1, int 
   c.ws.release(mk);   // stream-ordered: later kernels that reuse this memory run after the GN kernels
 }
 
+// MX-fp8 image of a LayerNorm output for the fp8 linear path: carved from c.ws by the caller's mark, filled by layernorm()
+struct QAct { unsigned char* a8 = nullptr; unsigned* sa = nullptr; long ld = 0; };
+static QAct qact_alloc(Ctx& c, long M, int K) {
+  QAct q; q.a8 = (unsigned char*)c.ws.alloc((size_t)M * K); q.ld = pad256(M);
+  q.sa = (unsigned*)c.ws.alloc((size_t)(K / 128) * q.ld * 4);
+  return q;
+}
 static void layernorm(Ctx& c, const f16* x, long M, const Norm& n, f16* y, const f16* addvec = nullptr,
-                      long rows_per_vec = 1, f16* xout = nullptr) {
+                      long rows_per_vec = 1, f16* xout = nullptr, const QAct* q = nullptr) {
   LayerNormP p; memset(&p, 0, sizeof(p));
   p.X = x; p.Y = y; p.M = (int)M; p.C = n.c; p.eps = n.eps; p.gamma = n.g; p.beta = n.b;
   p.addvec = addvec; p.rows_per_vec = (int)rows_per_vec; p.Xout = xout;
+  if (q) { p.Y8 = q->a8; p.S8 = q->sa; p.ld_s8 = q->ld; }
   ProfScope ps(c, "layernorm", 0, (double)M * n.c * 2.0 * (addvec ? 3.0 : 2.0));
   launch_layernorm(p, c.stream);
 }
@@ -759,7 +773,7 @@ static f16* stres_forward(Ctx& c, const STRes& rb, const f16* x0, int C0, const 
 // what survives in the 256 MiB Infinity Cache between the two GEMMs (level 0: 197 MB), the pair CAN run in row chunks so
 // each chunk's intermediate is consumed while still cache resident (rows are independent in both GEMMs).  Measured on
 // MI355X: -3 % end to end (the smaller launches lose more than residency gains), so it is opt-in (UG_FF_CHUNK=1).
-static void ff_pair(Ctx& c, const f16* a, long M, const Lin& f1, const Lin& f2, f16* mid, f16* out, const Epi& e2) {
+static void ff_pair(Ctx& c, const f16* a, long M, const Lin& f1, const Lin& f2, f16* mid, f16* out, const Epi& e2, const QAct* q = nullptr) {
   const int C4 = f1.out / 2, C = f2.out;
   // narrow blocks (level 0: C = 320): one fused kernel, the [M, 4C] intermediate never leaves the CU (kernels/ff_fused.hip)
   if (c.ff_fused && !c.fp8_linears && ff_fused_supported(C) && f1.in == C && C4 == 4 * C && M >= 32768 && f1.b && !e2.act && !e2.flags &&
@@ -780,7 +794,7 @@ static void ff_pair(Ctx& c, const f16* a, long M, const Lin& f1, const Lin& f2, 
   const long rows = ((M + nchunk - 1) / nchunk + 255) / 256 * 256;
   for (long r0 = 0; r0 < M; r0 += rows) {
     const long m = std::min(rows, M - r0);
-    { Epi e; e.flags = UG_F_GEGLU; linear(c, a + r0 * f1.in, m, f1, mid + r0 * C4, e); }
+    { Epi e; e.flags = UG_F_GEGLU; if (q && nchunk == 1) { e.a8 = q->a8; e.sa8 = q->sa; e.ld_sa8 = q->ld; } linear(c, a + r0 * f1.in, m, f1, mid + r0 * C4, e); }
     Epi e = e2;
     if (e.R1) e.R1 += r0 * (e.ldr1 ? e.ldr1 : C);
     if (e.R2) e.R2 += r0 * (e.ldr2 ? e.ldr2 : C);
@@ -797,10 +811,15 @@ static f16* transformer_forward(Ctx& c, const Transformer& tr, const f16* x, int
   groupnorm(c, x, C, nullptr, 0, T, HW, G, tr.gn, 0, 0, t1);
   f16* h0 = c.ws.get<f16>(M * C);
   linear(c, t1, M, tr.proj_in, h0);
+  // fp8 linear path: the LayerNorms feeding a linear layer write MX-fp8 directly (no fp16 copy, no separate quantiser pass)
+  const bool q8 = c.fp8_linears && !getenv("UG_NO_LNQ") && C % 128 == 0 && M >= 256 && tr.qkv1.w8 && tr.ff1.w8 && tr.ffin1.w8 && tr.tqkv.w8 && tr.tff1.w8;
+  QAct qa; if (q8) qa = qact_alloc(c, M, C);
+  const QAct* qp = q8 ? &qa : nullptr;
+  auto qepi = [&](Epi e) { if (q8) { e.a8 = qa.a8; e.sa8 = qa.sa; e.ld_sa8 = qa.ld; } return e; };
   // ---- spatial block
-  layernorm(c, h0, M, tr.ln1, t1);
+  layernorm(c, h0, M, tr.ln1, t1, nullptr, 1, nullptr, qp);
   f16* qkv = c.ws.get<f16>(M * 3 * C);
-  linear(c, t1, M, tr.qkv1, qkv);
+  linear(c, t1, M, tr.qkv1, qkv, qepi(Epi()));
   f16* ao = c.ws.get<f16>(M * C);
   {
     FlashP p; p.Q = qkv; p.K = qkv + C; p.V = qkv + 2 * C; p.ldq = p.ldk = p.ldv = 3 * C; p.O = ao; p.ldo = C;
@@ -814,17 +833,17 @@ static f16* transformer_forward(Ctx& c, const Transformer& tr, const f16* x, int
   f16* h1 = c.ws.get<f16>(M * C);
   { Epi e; e.R1 = h0; linear(c, ao, M, tr.o1, h1, e); }
   f16* h2 = c.ws.get<f16>(M * C);
-  layernorm(c, h1, M, tr.ln3, t1, tr.cross_sp, HW, h2);
+  layernorm(c, h1, M, tr.ln3, t1, tr.cross_sp, HW, h2, qp);
   f16* ffm = c.ws.get<f16>(M * 4 * C);
   f16* hs = c.ws.get<f16>(M * C);
-  { Epi e; e.R1 = h2; ff_pair(c, t1, M, tr.ff1, tr.ff2, ffm, hs, e); }
+  { Epi e; e.R1 = h2; ff_pair(c, t1, M, tr.ff1, tr.ff2, ffm, hs, e, qp); }
   // ---- temporal block (token order kept; only the attention gathers over frames)
   f16* xm = h0;   // h0 is dead
-  layernorm(c, hs, M, tr.ln_in, t1, tr.frame_emb, HW, xm);
+  layernorm(c, hs, M, tr.ln_in, t1, tr.frame_emb, HW, xm, qp);
   f16* g1 = h1;   // h1 is dead
-  { Epi e; e.R1 = xm; ff_pair(c, t1, M, tr.ffin1, tr.ffin2, ffm, g1, e); }
-  layernorm(c, g1, M, tr.tln1, t1);
-  linear(c, t1, M, tr.tqkv, qkv);
+  { Epi e; e.R1 = xm; ff_pair(c, t1, M, tr.ffin1, tr.ffin2, ffm, g1, e, qp); }
+  layernorm(c, g1, M, tr.tln1, t1, nullptr, 1, nullptr, qp);
+  linear(c, t1, M, tr.tqkv, qkv, qepi(Epi()));
   {
     TemporalAttnP p; p.Q = qkv; p.K = qkv + C; p.V = qkv + 2 * C; p.ld = 3 * C; p.O = ao; p.ldo = C;
     p.T = T; p.HW = HW; p.H = tr.heads; p.scale = 0.125f;
@@ -834,9 +853,9 @@ static f16* transformer_forward(Ctx& c, const Transformer& tr, const f16* x, int
   f16* g2 = h2;   // h2 is dead
   { Epi e; e.R1 = g1; linear(c, ao, M, tr.to1, g2, e); }
   f16* g3 = xm;   // xm is dead
-  layernorm(c, g2, M, tr.tln3, t1, tr.cross_tm, M, g3);
+  layernorm(c, g2, M, tr.tln3, t1, tr.cross_tm, M, g3, qp);
   f16* mix = g1;
-  { Epi e; e.c0 = 1.f - tr.alpha; e.R1 = g3; e.c1 = 1.f - tr.alpha; e.R2 = hs; e.c2 = tr.alpha; ff_pair(c, t1, M, tr.tff1, tr.tff2, ffm, mix, e); }
+  { Epi e; e.c0 = 1.f - tr.alpha; e.R1 = g3; e.c1 = 1.f - tr.alpha; e.R2 = hs; e.c2 = tr.alpha; ff_pair(c, t1, M, tr.tff1, tr.tff2, ffm, mix, e, qp); }
   { Epi e; e.R1 = x; linear(c, mix, M, tr.proj_out, out, e); }
   c.ws.release(mk);
   return out;

@@ -396,7 +396,25 @@ __global__ __launch_bounds__(256) void ln_kernel(const LayerNormP p) {
       f16x8 y;
 #pragma unroll
       for (int e = 0; e < 8; ++e) y[e] = (f16)((x[k][e] - mean) * rstd * (float)g[e] + (float)b[e]);
-      *(f16x8*)(p.Y + row * p.C + v * 8) = y;
+      if (!p.Y8) { *(f16x8*)(p.Y + row * p.C + v * 8) = y; continue; }
+      // MX-fp8 output (kernels/mx8.hip semantics on the fp16-rounded values): the 4 lanes 4j..4j+3 hold one 32-element block
+      float amax = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf((float)y[e]));
+      amax = fmaxf(amax, __shfl_xor(amax, 1));
+      amax = fmaxf(amax, __shfl_xor(amax, 2));
+      int ex = 0;
+      if (amax > 0.f) { (void)frexpf(amax, &ex); ex = ex - 1 - 8; }
+      ex = min(max(ex, -127), 127);
+      const float inv = ldexpf(1.0f, -ex);
+      float t[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = fminf(fmaxf((float)y[e] * inv, -448.f), 448.f);
+      int p0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], 0, false); p0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], p0, true);
+      int p1 = __builtin_amdgcn_cvt_pk_fp8_f32(t[4], t[5], 0, false); p1 = __builtin_amdgcn_cvt_pk_fp8_f32(t[6], t[7], p1, true);
+      *(uint2*)(p.Y8 + row * p.C + v * 8) = make_uint2((unsigned)p0, (unsigned)p1);
+      if ((lane & 3) == 0)   // one byte per block: dword (K step = v / 16, row), byte (v % 16) / 4
+        ((unsigned char*)(p.S8 + (long)(v >> 4) * p.ld_s8 + row))[(v & 15) >> 2] = (unsigned char)(ex + 127);
     }
   }
 }
@@ -405,6 +423,7 @@ void launch_layernorm(const LayerNormP& p, hipStream_t s) {
   UG_REQUIRE(p.C % 8 == 0, "LayerNorm C must be a multiple of 8");
   const int vpl = cdiv(p.C / 8, 64);
   UG_REQUIRE(vpl <= 4, "LayerNorm C too large");
+  if (p.Y8) UG_REQUIRE(p.C % 128 == 0 && p.S8 && p.ld_s8 >= p.M, "LayerNorm MX-fp8 output needs C % 128 == 0 and a scale buffer");
   dim3 grid(cdiv(p.M, 4)), block(256);
   switch (vpl) {
     case 1: hipLaunchKernelGGL(ln_kernel<1>, grid, block, 0, s, p); break;
