@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the with-normals / N=5 / fp16-encoder / fp8 side rates (rocprofv3 runs)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path (RCCL process group, all_gather, barriers, "
                     "max-over-ranks timing) even with one rank - plumbing check for the N > 1 launch on a 1-GPU box")
     ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4]: run the UNet transformers' linear layers on MX-fp8 matrix instructions "
@@ -262,7 +263,7 @@ def main():
             if full:
                 clip_tflop = a.denoise_steps * TFLOP_UNET + TFLOP_VAE_ENC + TFLOP_VAE_DEC + TFLOP_CLIP
                 res["pipeline_tflops"] = round(clip_tflop / (ms * 1e-3), 1)
-        if full and not a.no_profile:
+        if full and not a.no_profile and not a.no_extras:
             # also report the rate with prepare_output's normals inside the call, the reference-as-shipped N = 5 rate
             # (model/depthcrafter.py:86) and the cost of the reference-faithful float32 VAE encoder vs the fp16-storage one
             def rate(n, steps, **kw):

@@ -113,3 +113,36 @@ def test_stablenormal_ddim_tables_and_plugin_refusal():
     from unigeo_amd.model import StableNormal
     with pytest.raises(FileNotFoundError):
         StableNormal(model_dir="/nonexistent/dir")
+
+
+def test_stablenormal_checkpoint_directory_round_trip(tmp_path):
+    """load_stablenormal_pretrained on a tiny checkpoint directory in the documented layout (S11): every component is checked against
+    its manifest, DINO's larger position table is resampled to the tower's grid, a stray tensor is refused with a precise message."""
+    import numpy as np
+    import pytest
+    from safetensors.numpy import save_file
+    from unigeo_amd import weights as W
+    from unigeo_amd.stablenormal import COMPONENTS, manifests
+    cfgs = W.tiny_sn_cfgs()
+    ms = manifests(cfgs)
+    states = {c: W.random_state(ms[c], 3 + i) for i, c in enumerate(COMPONENTS)}
+    d = cfgs[2].hidden_size
+    big = np.random.default_rng(0).standard_normal((1, 1 + 37 * 37, d)).astype(np.float16)      # a 518 / 14 = 37 x 37 table, as dinov2 ships
+    for c in COMPONENTS:
+        (tmp_path / c).mkdir()
+        st = dict(states[c])
+        if c == "dino":
+            st["pos_embed"] = big; st["mask_token"] = np.zeros((1, d), np.float16)
+        save_file(st, str(tmp_path / c / ("model.safetensors" if c == "dino" else "diffusion_pytorch_model.fp16.safetensors")))
+    pe = np.random.default_rng(1).standard_normal((77, cfgs[0].cross_attention_dim)).astype(np.float32)
+    np.save(tmp_path / "prompt_embeds.npy", pe)
+    got, prompt = W.load_stablenormal_pretrained(str(tmp_path), cfgs)
+    assert np.array_equal(prompt, pe)
+    for c in COMPONENTS:
+        assert set(got[c]) == set(ms[c]) and all(tuple(got[c][k].shape) == tuple(v) for k, v in ms[c].items()), c
+    assert got["dino"]["pos_embed"].shape == (1, 257, d) and np.array_equal(got["dino"]["pos_embed"][:, 0], big[:, 0].astype(np.float32))
+    assert np.array_equal(got["unet"]["conv_in.weight"], states["unet"]["conv_in.weight"])
+    st = dict(states["unet"]); st["surprise.weight"] = np.zeros((2, 2), np.float16)
+    save_file(st, str(tmp_path / "unet" / "diffusion_pytorch_model.fp16.safetensors"))
+    with pytest.raises(ValueError, match="unexpected 1"):
+        W.load_stablenormal_pretrained(str(tmp_path), cfgs)

@@ -71,6 +71,8 @@ struct GemmP {
   const unsigned* sa; const unsigned* sw; long ld_sa, ld_sw;
   int kchunk;            // im2col K order: 0 = [tap][channel] (weights [N][taps][C]); 1 = [64-channel chunk][tap][64] - all taps of a chunk are
                          // consecutive K steps, so the activation rows a tile re-reads per tap are still in the XCD's L2 (needs (C0+C1) % 64 == 0)
+  int tm_T, tm_nb;       // temporal conv (kt > 1): walk the M tiles frame-fastest - walk index i -> tile (i % tm_T) * tm_nb + i / tm_T, so the tiles of one
+                         // pixel block in neighbouring frames (which read each other's rows as taps) run together; 0 = off (needs Ho*Wo % BM == 0)
   int group_m;           // tile walk: 0 / 1 = row-major, g > 1 = g M-tiles x all N tiles column by column (set by launch_gemm; see tile_coord)
 };
 void launch_gemm_mx8(const GemmP& p, hipStream_t s);   // dense only; C0 = lda and ldw in BYTES (= elements)

@@ -77,6 +77,11 @@ __device__ __forceinline__ void tile_coord(int tile, int ntm, int ntn, int group
   tn = local / gm;
   tm = first + (local - tn * gm);
 }
+// + the frame-fastest permutation of the M tiles for temporal convolutions (GemmP::tm_T)
+__device__ __forceinline__ void tile_coord_p(const GemmP& p, int tile, int ntm, int ntn, int& tm, int& tn) {
+  tile_coord(tile, ntm, ntn, p.group_m, tm, tn);
+  if (p.tm_T) { const int q = tm / p.tm_T; tm = (tm - q * p.tm_T) * p.tm_nb + q; }
+}
 
 // waves per SIMD the LDS footprint allows (workgroups per CU x waves per workgroup / 4 SIMDs): handed to
 // __launch_bounds__ so the register allocator does not trade that occupancy away.
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
 
   int ld_m0 = 0, ld_n0 = 0;   // MX: origin of the tile being fetched (scale rows)
   auto setup_tile = [&](int tile) {
-    int tm, tn; tile_coord(tile, ntm, ntn, p.group_m, tm, tn);
+    int tm, tn; tile_coord_p(p, tile, ntm, ntn, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     ld_m0 = m0; ld_n0 = n0;
 #pragma unroll
@@ -602,7 +607,7 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
     // ---- tile finished: epilogue (the next tile's operands keep streaming into the ring meanwhile) ----
     drain = true;
     const int tile = wslot + ti * nwg;
-    { int etm, etn; tile_coord(tile, ntm, ntn, p.group_m, etm, etn); tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
+    { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn); tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
   }
 }
 
@@ -674,7 +679,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ldr_kernel(const GemmP p) {
   const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, (int)SENT, 0x00020000);
 
   auto setup_tile = [&](int tile) {
-    int tm, tn; tile_coord(tile, ntm, ntn, p.group_m, tm, tn);
+    int tm, tn; tile_coord_p(p, tile, ntm, ntn, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 #pragma unroll
     for (int l = 0; l < LA; ++l) {
@@ -834,7 +839,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ldr_kernel(const GemmP p) {
     cp_ks = 0;
     const int tile = wslot + (cp_ti++) * nwg;
     drain = true;
-    { int etm, etn; tile_coord(tile, ntm, ntn, p.group_m, etm, etn); tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
+    { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn); tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
   }
 }
 
@@ -927,7 +932,7 @@ __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(const GemmP p) {
     auto issue = [&]() {
       if (ld_ks == 0) {
         const int tile = wslot + ld_ti * nwg;
-        int tm, tn; tile_coord(tile, ntm, ntn, p.group_m, tm, tn);
+        int tm, tn; tile_coord_p(p, tile, ntm, ntn, tm, tn);
         const int m0 = tm * BM, n0 = tn * BN;
 #pragma unroll
         for (int l = 0; l < LA; ++l) {
@@ -1085,7 +1090,7 @@ __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(const GemmP p) {
     if (++cp_ks == nk) {
       cp_ks = 0;
       const int tile = wslot + (cp_ti++) * nwg;
-      { int etm, etn; tile_coord(tile, ntm, ntn, p.group_m, etm, etn); tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
+      { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn); tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all fragment reads of this slot are done before it is handed back
     UG_STAMP(2);
@@ -1420,6 +1425,13 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
   p.splitk = split;
   if (split > 1) UG_REQUIRE(p.partial != nullptr, "split-K needs a partial buffer");
   p.group_m = pick_group_m(p, cfg, batch, split);
+  p.tm_T = p.tm_nb = 0;
+  if (p.conv && p.kt > 1 && p.T > 1 && batch == 1 && !(g_knobs & 256)) {   // knob 256: frame-major M walk for temporal convs (A/B)
+    int bm = 256;
+    switch (cfg) { case 0: case 1: case 3: bm = 128; break; case 12: bm = 64; break; default: break; }
+    const long hw = (long)p.Ho * p.Wo;
+    if (hw % bm == 0 && hw / bm >= 1) { p.tm_T = p.T; p.tm_nb = (int)(hw / bm); }
+  }
   launch_cfg(cfg, p, batch, s);
   if (split > 1) {
     const long nvec = (long)p.M * (p.N / 8);

@@ -94,9 +94,9 @@ class StableNormalPredictorHIP:
         return cls.from_states(states, cfgs, prompt_embeds=pe, **kw)
 
     @classmethod
-    def from_pretrained(cls, model_dir, **kw):
-        states, pe = W.load_stablenormal_pretrained(model_dir)
-        return cls.from_states(states, prompt_embeds=pe, **kw)
+    def from_pretrained(cls, model_dir, cfgs=None, **kw):
+        states, pe = W.load_stablenormal_pretrained(model_dir, cfgs)
+        return cls.from_states(states, cfgs, prompt_embeds=pe, **kw)
 
     def predict_batch(self, images01):
         """[B,H,W,3] float in [0,1] -> unit normals [B,H,W,3] float32 in [-1,1] (one ug_sn_run call)."""

@@ -464,13 +464,13 @@ def dino_manifest(cfg: DinoCfg = DinoCfg()) -> "OrderedDict[str, tuple]":
     return m
 
 
-def load_stablenormal_pretrained(model_dir: str):
+def load_stablenormal_pretrained(model_dir: str, cfgs=None):
     """Checkpoint directory -> ({component: state}, prompt_embeds [77,1024]).  Expected layout (diffusers-style, one sub-directory per
     component; S11): ``vae/``, ``unet_yoso/``, ``controlnet_yoso/``, ``unet/``, ``controlnet_dino/`` each with
     ``diffusion_pytorch_model[.fp16].safetensors``; ``dino/model.safetensors`` (dinov2 hub naming); ``text_encoder/`` + ``tokenizer/``
     (transformers CLIPTextModel - run ONCE here, on the host, for the fixed prompt) or a precomputed ``prompt_embeds.npy``.
     Every state dict is checked against the manifest; DINO's 37x37 position table is resampled (bicubic) to the tower's grid."""
-    cfgs = (SDUNetCfg(), VAECfg(), DinoCfg())
+    cfgs = cfgs or (SDUNetCfg(), VAECfg(), DinoCfg())
     names = ["diffusion_pytorch_model.fp16.safetensors", "diffusion_pytorch_model.safetensors", "model.fp16.safetensors", "model.safetensors"]
     man = {"vae": sd_vae_manifest(cfgs[1]), "unet_yoso": sd_unet_manifest(cfgs[0]), "controlnet_yoso": controlnet_manifest(cfgs[0]),
            "unet": sd_unet_manifest(cfgs[0]), "controlnet_dino": controlnet_manifest(cfgs[0], cfgs[2].hidden_size), "dino": dino_manifest(cfgs[2])}
