@@ -152,19 +152,27 @@ __global__ __launch_bounds__(256) void k_gn32_stats4(const Gn32P p, int nchunk, 
 }
 
 __global__ __launch_bounds__(256) void k_gn32_finalize(const Gn32P p, int nchunk) {
-  const int t = blockIdx.x, g = threadIdx.x;
-  if (g >= p.G) return;
+  // grid (T); 256 / G threads share one group's chunk partials (fixed order: deterministic), then a short LDS combine
+  __shared__ double sa[256], sb[256];
+  const int t = blockIdx.x, tid = threadIdx.x, G = p.G;
+  const int SUB = 256 / G, g = tid % G, sub = tid / G;
   double a = 0.0, b = 0.0;
-  for (int ch = 0; ch < nchunk; ++ch) {
-    const double* d = p.part + (((long)t * nchunk + ch) * p.G + g) * 2;
-    a += d[0]; b += d[1];
+  if (sub < SUB)
+    for (int ch = sub; ch < nchunk; ch += SUB) {
+      const double* d = p.part + (((long)t * nchunk + ch) * G + g) * 2;
+      a += d[0]; b += d[1];
+    }
+  sa[tid] = a; sb[tid] = b;
+  __syncthreads();
+  if (tid < G) {
+    for (int s2 = 1; s2 < SUB; ++s2) { a += sa[tid + s2 * G]; b += sb[tid + s2 * G]; }
+    const double n = (double)(p.C / G) * p.HW;
+    const double mean = a / n;
+    double var = b / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    p.mr[((long)t * G + tid) * 2 + 0] = (float)mean;
+    p.mr[((long)t * G + tid) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
   }
-  const double n = (double)(p.C / p.G) * p.HW;
-  const double mean = a / n;
-  double var = b / n - mean * mean;
-  if (var < 0.0) var = 0.0;
-  p.mr[((long)t * p.G + g) * 2 + 0] = (float)mean;
-  p.mr[((long)t * p.G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
 }
 
 __global__ __launch_bounds__(256) void k_gn32_apply(const Gn32P p, int rpc) {
