@@ -1370,6 +1370,22 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
       }
       if (split == 1 && nk >= 48) split = 2;
     }
+    // Few-tile corner (a batch-1 StableNormal image: 81 / 324 / 1296 rows; tools/tune_splitk_small.py, profiles/r02_splitk_small_m.txt):
+    // the launch has to be spread over the CUs along K.  im2col: 128x128 tiles, ~480 workgroups, >= 7 K steps per slice (conv1280@9x9
+    // 62 -> 36 us, conv640@36x36 108 -> 58 us); dense: the 3-stage 128x64 tile, ~256 workgroups, >= 5 K steps per slice.
+    if (plain_epi && p.N >= 128) {
+      const long t64 = (long)cdiv(p.M, 128) * cdiv(p.N, 64);
+      if (p.conv && tiles128 <= 64 && nk >= 64) {
+        int sp = (int)std::min<long>(std::min<long>(512 / tiles128, nk / 7), 24);
+        while (sp >= 2 && (512 / sp) / 8 * 8 < tiles128) --sp;     // the persistent grid (a multiple of 8 per K slice) must hold every tile in one round
+        if (sp >= 2) { cfg = 0; split = sp; }
+      } else if (!p.conv && t64 <= 64 && nk >= 16) {
+        const int sp = (int)std::min<long>(256 / t64, nk / 5);
+        if (sp >= 2) { cfg = 3; split = sp; }
+      }
+    }
+  } else if (!geglu && !p.conv && p.M <= 512 && p.N >= 2048) {
+    cfg = 3;   // wide projection of a few rows: many small tiles beat a handful of large ones (324x3840x1280: 14.4 vs 19.3 us)
   } else if (plain_epi && p.conv && p.M <= 8192 && nk >= 256 && p.N >= 512) {
     cfg = 0; split = 4;   // 12x16 level, concatenated 2560-channel input: four K slices fill the last round (880 vs 816 TFLOP/s)
   }
