@@ -1,6 +1,7 @@
 // Engine core: arena, weight binding (diffusers / transformers state-dict names -> kernel-ready
 // fp16 layouts), op wrappers with optional HIP-event profiling.
 #include "engine.h"
+#include <chrono>
 
 #include <math.h>
 #include <stdlib.h>
@@ -1333,6 +1334,9 @@ void dc_run(Ctx& c, int steps, int chunk, int with_normals, int window, int over
     unet_prepare(c, T, emb, ts.data(), steps);
     f16* xin = c.ws.get<f16>(lp * 8);
     // 5. denoise loop: no host sync inside
+    const bool host_timing = getenv("UG_HOST_TIMING") != nullptr;   // measurement aid: is the host ahead of the stream?
+    if (host_timing) UG_CHECK(hipStreamSynchronize(c.stream));
+    const auto ht0 = std::chrono::steady_clock::now();
     for (int i = 0; i < steps; ++i) {
       const size_t m2 = c.ws.mark();
       launch_make_unet_input(lat, cond, xin, lp, sqrtf(sig[i] * sig[i] + 1.f), c.stream);
@@ -1345,6 +1349,13 @@ void dc_run(Ctx& c, int steps, int chunk, int with_normals, int window, int over
         UG_CHECK(hipStreamSynchronize(c.stream));
       }
       c.ws.release(m2);
+    }
+    if (host_timing) {
+      const auto ht1 = std::chrono::steady_clock::now();
+      UG_CHECK(hipStreamSynchronize(c.stream));
+      const auto ht2 = std::chrono::steady_clock::now();
+      fprintf(stderr, "[ug] denoise loop: host enqueue %.1f ms, stream done after %.1f ms\n",
+              std::chrono::duration<double, std::milli>(ht1 - ht0).count(), std::chrono::duration<double, std::milli>(ht2 - ht0).count());
     }
   } else {
     const long fe = (long)h * w * 4;                     // latent elements per frame

@@ -17,6 +17,7 @@
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __fp16 h4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 // K tile swizzle (read with ds_read_b128 by 32 different rows, same logical chunk)
@@ -102,14 +103,24 @@ __device__ __forceinline__ void fa_tile(const f16* kt, const f16* vt, const f16x
           for (int r = 0; r < 16; ++r) o[qb][dt][r] *= alpha;
         m_run[qb] = m_new;
       }
-      float ps = 0.f;
+      // packed fp32 (v_pk_fma_f32 / v_pk_add_f32): two scores per VALU instruction - the loop is VALU-bound (16 exp2 per 32 keys)
+      const f32x2 sc2 = {sc, sc}, nm2 = {-m_run[qb], -m_run[qb]};
+      f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -m_run[qb]));
-        ps += e;
-        pb[qb][r >> 3][r & 7] = (f16)e;
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 sv = {s[r], s[r + 1]};
+#ifdef FA_SCALAR
+        const f32x2 e2 = {__builtin_amdgcn_exp2f(fmaf(sv.x, sc, nm2.x)), __builtin_amdgcn_exp2f(fmaf(sv.y, sc, nm2.y))};
+        ps2.x += e2.x; ps2.y += e2.y;
+#else
+        const f32x2 tt = sv * sc2 + nm2;
+        const f32x2 e2 = {__builtin_amdgcn_exp2f(tt.x), __builtin_amdgcn_exp2f(tt.y)};
+        ps2 += e2;
+#endif
+        pb[qb][r >> 3][r & 7] = (f16)e2.x;
+        pb[qb][r >> 3][(r & 7) + 1] = (f16)e2.y;
       }
-      l_run[qb] += ps;
+      l_run[qb] += ps2.x + ps2.y;
     }
     // O^T += V^T P^T : every V^T fragment (two transpose reads) feeds both query blocks
 #pragma unroll
@@ -172,16 +183,20 @@ __device__ __forceinline__ void fa_tile_wide(const f16* kt, const f16* vt, const
     m_run[0] = m_new;
   }
   f16x8 pb[2][2];
-  float ps = 0.f;
+  const f32x2 sc2 = {sc, sc}, nm2 = {-m_run[0], -m_run[0]};
+  f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float e = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sc, -m_run[0]));
-      ps += e;
-      pb[kb][r >> 3][r & 7] = (f16)e;
+    for (int r = 0; r < 16; r += 2) {
+      const f32x2 sv = {s[kb][r], s[kb][r + 1]};
+      const f32x2 tt = sv * sc2 + nm2;
+      const f32x2 e2 = {__builtin_amdgcn_exp2f(tt.x), __builtin_amdgcn_exp2f(tt.y)};
+      ps2 += e2;
+      pb[kb][r >> 3][r & 7] = (f16)e2.x;
+      pb[kb][r >> 3][(r & 7) + 1] = (f16)e2.y;
     }
-  l_run[0] += ps;
+  l_run[0] += ps2.x + ps2.y;
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -201,16 +216,25 @@ __device__ __forceinline__ void fa_tile_wide(const f16* kt, const f16* vt, const
       }
 }
 
-static int g_fa_wide = 0;   // A/B knob (ug_tune_flash): 1 = fa_tile_wide
+static int g_fa_wide = 3;   // A/B knob (ug_tune_flash): bit 0 = fa_tile_wide, bit 1 = XCD-grouped workgroup order
 void flash_set_variant(int v) { g_fa_wide = v; }
 
+// The grid is 1-D: workgroup L runs on XCD L % 8, and each XCD has its own L2.  With the natural order the query blocks of one
+// (frame, head) are dealt round-robin to all 8 XCDs, so every L2 fetches that head's K / V for itself; the permutation below hands each
+// XCD a contiguous run of (frame, head, query-block) triples instead, so the K / V of a head are fetched into ONE L2.
 template <bool WIDE>
-__global__ __launch_bounds__(256, 3) void flash_attn64_kernel(const FlashP p) {
+__global__ __launch_bounds__(256, 3) void flash_attn64_kernel(const FlashP p, int nqb, int xcd_group) {
   __shared__ __attribute__((aligned(16))) f16 lds[FA_NST * 2 * FA_KV * 64];  // [slot][K|V][64][64]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * (128 * FA_QB) + wave * (32 * FA_QB);
+  int L = blockIdx.x;
+  if (xcd_group) {
+    const int per = gridDim.x >> 3;                  // gridDim.x % 8 == 0 when xcd_group is set
+    L = (L & 7) * per + (L >> 3);
+  }
+  const int bx = L % nqb, bh = L / nqb;
+  const int h = bh % p.H, b = bh / p.H;
+  const int q0 = bx * (128 * FA_QB) + wave * (32 * FA_QB);
   const long row0 = (long)b * p.S;
   const int Sk = p.Sk ? p.Sk : p.S;                       // cross-attention: keys / values have their own length ...
   const long rowk = p.kv_shared ? 0 : (long)b * Sk;       // ... and may be one context shared by every batch
@@ -266,7 +290,8 @@ __global__ __launch_bounds__(256, 3) void flash_attn64_kernel(const FlashP p) {
   for (int s0 = 0; s0 < FA_NST - 1; ++s0)
     if (s0 < ntile) stage(s0 * FA_KV, s0);
   int buf = 0, ld = FA_NST - 1;   // ring slots of the tile being consumed / the next tile to fetch
-  for (int t = 0; t < ntile; ++t) {
+  // wait for tile t, hand its slot over, start the fetch of tile t + FA_NST - 1
+  auto advance = [&](int t) {
     // each thread issued 4 loads per tile; up to FA_NST-2 younger tiles may stay in flight
     const int younger = min(FA_NST - 2, ntile - 1 - t);
     if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -276,16 +301,22 @@ __global__ __launch_bounds__(256, 3) void flash_attn64_kernel(const FlashP p) {
     asm volatile("" ::: "memory");
     if (t + FA_NST - 1 < ntile) { stage((t + FA_NST - 1) * FA_KV, ld); }
     if (++ld == FA_NST) ld = 0;
+  };
+  // full tiles, then (peeled, so the two bodies never merge their register assignments) the ragged last one
+  for (int t = 0; t < nfull; ++t) {
+    advance(t);
     const f16* kt = lds + buf * (2 * FA_KV * 64);
     const f16* vt = kt + FA_KV * 64;
-    if (WIDE) {
-      if (t < nfull) fa_tile_wide<false>(kt, vt, qf, lane, t * FA_KV, Sk, sc, m_run, l_run, o);
-      else fa_tile_wide<true>(kt, vt, qf, lane, t * FA_KV, Sk, sc, m_run, l_run, o);
-    } else {
-      if (t < nfull) fa_tile<false>(kt, vt, qf, lane, t * FA_KV, Sk, sc, m_run, l_run, o);
-      else fa_tile<true>(kt, vt, qf, lane, t * FA_KV, Sk, sc, m_run, l_run, o);
-    }
+    if (WIDE) fa_tile_wide<false>(kt, vt, qf, lane, t * FA_KV, Sk, sc, m_run, l_run, o);
+    else fa_tile<false>(kt, vt, qf, lane, t * FA_KV, Sk, sc, m_run, l_run, o);
     if (++buf == FA_NST) buf = 0;
+  }
+  if (nfull < ntile) {
+    advance(nfull);
+    const f16* kt = lds + buf * (2 * FA_KV * 64);
+    const f16* vt = kt + FA_KV * 64;
+    if (WIDE) fa_tile_wide<true>(kt, vt, qf, lane, nfull * FA_KV, Sk, sc, m_run, l_run, o);
+    else fa_tile<true>(kt, vt, qf, lane, nfull * FA_KV, Sk, sc, m_run, l_run, o);
   }
 #pragma unroll
   for (int qb = 0; qb < FA_QB; ++qb) {
@@ -310,9 +341,12 @@ __global__ __launch_bounds__(256, 3) void flash_attn64_kernel(const FlashP p) {
 void launch_flash_attn64(const FlashP& p, hipStream_t s) {
   UG_REQUIRE(p.S >= 1 && p.B >= 1 && p.H >= 1, "flash attention shape");
   UG_REQUIRE(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0, "flash attention strides");
-  dim3 grid(cdiv(p.S, 128 * FA_QB), p.H, p.B);
-  if (g_fa_wide) hipLaunchKernelGGL(flash_attn64_kernel<true>, grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(flash_attn64_kernel<false>, grid, dim3(256), 0, s, p);
+  const int nqb = cdiv(p.S, 128 * FA_QB);
+  const long total = (long)nqb * p.H * p.B;
+  UG_REQUIRE(total < (1L << 31), "flash attention grid");
+  const int xcd_group = (total % 8 == 0 && (g_fa_wide & 2)) ? 1 : 0;
+  if (g_fa_wide & 1) hipLaunchKernelGGL(flash_attn64_kernel<true>, dim3((unsigned)total), dim3(256), 0, s, p, nqb, xcd_group);
+  else hipLaunchKernelGGL(flash_attn64_kernel<false>, dim3((unsigned)total), dim3(256), 0, s, p, nqb, xcd_group);
   UG_CHECK(hipGetLastError());
 }
 
