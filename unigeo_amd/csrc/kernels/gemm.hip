@@ -1384,6 +1384,20 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
         if (sp >= 2) { cfg = 3; split = sp; }
       }
     }
+  } else if (!(g_knobs & 512) && plain_epi && p.M <= 8192 && tiles128 <= 256 && p.N >= 128 && p.N < 2048 && (p.conv ? nk >= 32 : nk >= 16)) {
+    // Under-filled launch (a 72x72 / 36x36 latent of ONE image: 40 - 250 tiles of 128x128 for 256 CUs): the cost model above prices a
+    // round by its tile size only and keeps the 256x128 tile on 63 workgroups; what helps is workgroups - 128x128 (im2col) or 128x64
+    // (dense) tiles, K sliced until ~512 are in flight (knob 512 = off; tools/ab_sn.py)
+    if (p.conv) {
+      int sp = (int)std::min<long>(std::min<long>(512 / tiles128, nk / 8), 8);
+      while (sp >= 2 && (512 / sp) / 8 * 8 < tiles128) --sp;
+      cfg = 0; split = std::max(1, sp);
+    } else {
+      const long t64 = (long)cdiv(p.M, 128) * cdiv(p.N, 64);
+      cfg = 3;
+      const int sp = (int)std::min<long>(std::min<long>(512 / t64, nk / 8), 8);
+      split = std::max(1, sp);
+    }
   } else if (!geglu && !p.conv && p.M <= 512 && p.N >= 2048) {
     cfg = 3;   // wide projection of a few rows: many small tiles beat a handful of large ones (324x3840x1280: 14.4 vs 19.3 us)
   } else if (plain_epi && p.conv && p.M <= 8192 && nk >= 256 && p.N >= 512) {
