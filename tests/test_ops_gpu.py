@@ -412,3 +412,31 @@ def test_ff_fused_vs_reference_and_two_launch_path(engine, M, C):
     ref = (0.7 * (mid @ t(W2).T + t(b2)) + 1.3 * t(R1)).numpy()
     assert_close(got, ref, 2e-3, f"fused GEGLU feed-forward {M}x{C}")
     assert_close(got, two, 1.5e-3, f"fused vs two-launch feed-forward {M}x{C}")
+
+
+@pytest.mark.parametrize("M,C,rpv", [(300, 64, 0), (1000, 128, 250), (5000, 320, 1250), (4100, 320, 4100), (77, 256, 0)])
+def test_ff_fused_with_in_kernel_layernorm(engine, M, C, rpv):
+    """Pre-norm inside the fused feed-forward kernel (FFusedP::ln_g): x' = fp16(X + row vector), LayerNorm(x') on the LDS tile, residual x'.
+    Against fp32 torch on the fp16-rounded operands, and against the LayerNorm launch + fused / two-GEMM paths it replaces (the LayerNorm
+    values are rounded to fp16 at the same point in all three, so they agree to fp32-summation-order effects)."""
+    rng = np.random.default_rng(M + C)
+    I = 4 * C
+    X = h16(rng.standard_normal((M, C)) * 2.0 + 0.5)
+    gamma, beta = h16(1.0 + 0.2 * rng.standard_normal(C)), h16(0.1 * rng.standard_normal(C))
+    W1, b1 = h16(rng.standard_normal((2 * I, C)) / np.sqrt(C)), h16(rng.standard_normal(2 * I) * 0.1)
+    W2, b2 = h16(rng.standard_normal((C, I)) / np.sqrt(I)), h16(rng.standard_normal(C) * 0.1)
+    av = h16(rng.standard_normal(((M + rpv - 1) // rpv, C))) if rpv else None
+    kw = dict(addvec=av, rows_per_vec=max(rpv, 1), eps=1e-5, c0=0.7, c1=1.3)
+    got = engine.op_ln_ff(X, gamma, beta, W1, b1, W2, b2, mode=2, **kw)
+    one = engine.op_ln_ff(X, gamma, beta, W1, b1, W2, b2, mode=1, **kw)
+    two = engine.op_ln_ff(X, gamma, beta, W1, b1, W2, b2, mode=0, **kw)
+    xs = t(X)
+    if rpv:
+        xs = (xs + t(av)[torch.arange(M) // rpv]).half().float()
+    ln = torch.nn.functional.layer_norm(xs, (C,), t(gamma), t(beta), 1e-5).half().float()
+    h = ln @ t(W1).T + t(b1)
+    mid = (h[:, :I] * torch.nn.functional.gelu(h[:, I:])).half().float()
+    ref = (0.7 * (mid @ t(W2).T + t(b2)) + 1.3 * xs).numpy()
+    assert_close(got, ref, 2e-3, f"fused LayerNorm + feed-forward {M}x{C}")
+    assert_close(got, one, 1e-3, f"in-kernel LayerNorm vs LayerNorm launch + fused feed-forward {M}x{C}")
+    assert_close(got, two, 1.5e-3, f"in-kernel LayerNorm vs three launches {M}x{C}")

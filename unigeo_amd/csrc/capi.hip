@@ -123,7 +123,7 @@ int ug_dc_run_windows(ug_ctx* x, int steps, int chunk, int with_normals, int win
 }
 int ug_set_ff_fused(ug_ctx* x, int on) {
   if (!x) return -1;
-  x->c.ff_fused = on ? 1 : 0;
+  x->c.ff_fused = on & 3;   // bit 0: fused feed-forward kernel, bit 1: its pre-LayerNorm inside the kernel
   return 0;
 }
 int ug_set_fp8_linears(ug_ctx* x, int on) {
@@ -464,6 +464,54 @@ int ug_op_linear(ug_ctx* x, const float* A, int M, int K, const float* W, int N,
     { int cf, sp; gemm_plan(p, 1, &cf, &sp); p.cfg_p1 = cf + 1; p.splitk = sp; if (sp > 1) p.partial = c.ws.get<float>((long)sp * M * N); }
     launch_gemm(p, 1, c.stream);
     down16(c, dO, out, (long)M * Nout);
+  });
+}
+
+// out = c0 * FF(LayerNorm(x') * gamma + beta) + c1 * x',  x' = fp16(X + addvec[row / rows_per_vec]) (addvec may be NULL: x' = X).
+// mode 0: LayerNorm launch + two GEMM launches; 1: LayerNorm launch + fused feed-forward; 2: everything inside the fused kernel.
+int ug_op_ln_ff(ug_ctx* x, const float* X, int M, int C, const float* gamma, const float* beta, float eps, const float* addvec, int rows_per_vec,
+                const float* W1, const float* b1, const float* W2, const float* b2, float c0, float c1, int mode, float* out) {
+  UG_TRY(x, {
+    Ctx& c = x->c; Scope sc(c);
+    const int I = 4 * C;
+    std::vector<float> w1((size_t)2 * I * C), bb1((size_t)2 * I);
+    for (int v = 0; v < 2 * I; ++v) {
+      const int blk = v / 16, wv = v % 16, src = wv < 8 ? blk * 8 + wv : I + blk * 8 + (wv - 8);
+      memcpy(&w1[(size_t)v * C], &W1[(size_t)src * C], sizeof(float) * C);
+      bb1[v] = b1[src];
+    }
+    const int nvec = addvec ? (M + rows_per_vec - 1) / rows_per_vec : 0;
+    f16* dX = up16(c, X, (long)M * C); f16* dW1 = up16(c, w1.data(), (long)2 * I * C); f16* db1 = up16(c, bb1.data(), 2 * I);
+    f16* dW2 = up16(c, W2, (long)C * I); f16* db2 = up16(c, b2, C);
+    f16* dg = up16(c, gamma, C); f16* dbt = up16(c, beta, C); f16* dav = addvec ? up16(c, addvec, (long)nvec * C) : nullptr;
+    f16* dO = c.ws.get<f16>((long)M * C);
+    FFusedP p; memset(&p, 0, sizeof(p));
+    p.W1 = dW1; p.b1 = db1; p.W2 = dW2; p.b2 = db2; p.c0 = c0; p.c1 = c1; p.Out = dO; p.M = M; p.C = C; p.zero = c.zero;
+    if (mode == 2) {
+      p.X = dX; p.R1 = dX; p.ln_g = dg; p.ln_b = dbt; p.ln_eps = eps; p.addvec = dav; p.rows_per_vec = rows_per_vec;
+      launch_ff_fused(p, c.stream);
+    } else {
+      f16* t1 = c.ws.get<f16>((long)M * C); f16* xo = c.ws.get<f16>((long)M * C);
+      LayerNormP l; memset(&l, 0, sizeof(l));
+      l.X = dX; l.Y = t1; l.M = M; l.C = C; l.eps = eps; l.gamma = dg; l.beta = dbt; l.addvec = dav; l.rows_per_vec = rows_per_vec; l.Xout = dav ? xo : nullptr;
+      launch_layernorm(l, c.stream);
+      const f16* res = dav ? xo : dX;
+      if (mode == 1) {
+        p.X = t1; p.R1 = res;
+        launch_ff_fused(p, c.stream);
+      } else {
+        f16* mid = c.ws.get<f16>((long)M * I);
+        GemmP g1; memset(&g1, 0, sizeof(g1));
+        g1.A0 = t1; g1.C0 = C; g1.M = M; g1.N = 2 * I; g1.K = C; g1.W = dW1; g1.ldw = C; g1.bias = db1; g1.c0 = 1.f; g1.Out = mid; g1.ldo = I;
+        g1.flags = UG_F_GEGLU; g1.zero = c.zero; g1.nb_inner = 1;
+        launch_gemm(g1, 1, c.stream);
+        GemmP g2; memset(&g2, 0, sizeof(g2));
+        g2.A0 = mid; g2.C0 = I; g2.M = M; g2.N = C; g2.K = I; g2.W = dW2; g2.ldw = I; g2.bias = db2; g2.c0 = c0; g2.R1 = res; g2.ldr1 = C; g2.c1 = c1;
+        g2.Out = dO; g2.ldo = C; g2.zero = c.zero; g2.nb_inner = 1; g2.splitk = 1;
+        launch_gemm(g2, 1, c.stream);
+      }
+    }
+    down16(c, dO, out, (long)M * C);
   });
 }
 

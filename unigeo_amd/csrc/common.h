@@ -89,6 +89,10 @@ struct FFusedP {
   const f16* X; const f16* W1; const f16* b1; const f16* W2; const f16* b2;
   const f16* R1; const f16* R2; float c0, c1, c2;
   f16* Out; int M, C; const f16* zero;
+  // optional pre-norm, done on the X tile in LDS (what launch_layernorm would have written, same roundings):
+  //   x' = fp16(X + addvec[row / rows_per_vec]) (addvec optional), X_used = fp16(LayerNorm(x') * ln_g + ln_b);
+  // with addvec the R1 residual is taken as fp16(R1 + addvec[...]) as well (R1 == X: the block's residual stream)
+  const f16* ln_g; const f16* ln_b; float ln_eps; const f16* addvec; int rows_per_vec;
 };
 bool ff_fused_supported(int C);
 void launch_ff_fused(const FFusedP& p, hipStream_t s);

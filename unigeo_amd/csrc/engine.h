@@ -143,7 +143,8 @@ struct Ctx {
   size_t io_mark = 0; bool io_ready = false;
   // parity instrumentation: when set, dc_run copies the latents after every Euler step to this host buffer ([steps][T*h*w*4] f32)
   float* trace_host = nullptr; int trace_steps = 0;
-  int ff_fused = 1;          // fused GEGLU feed-forward kernel for the narrow (C <= 320) transformer blocks; 0 = two GEMM launches (A/B runs)
+  int ff_fused = 3;          // bit 0: fused GEGLU feed-forward kernel for the narrow (C <= 320) transformer blocks (0 = two GEMM launches);
+                             // bit 1: its LayerNorm (+ broadcast row added to the residual stream) applied inside that kernel (A/B runs)
   int fp8_linears = 0;       // 1 = run the UNet's eligible linear layers on MX-fp8 MFMAs (BASELINE configs[4]; reduced precision, off by default)
   int vae_encode_fp32 = 1;   // 1 = reference behaviour (float32-grade encoder), 0 = fp16 storage like the decoder
 };

@@ -774,14 +774,23 @@ static f16* stres_forward(Ctx& c, const STRes& rb, const f16* x0, int C0, const 
 // what survives in the 256 MiB Infinity Cache between the two GEMMs (level 0: 197 MB), the pair CAN run in row chunks so
 // each chunk's intermediate is consumed while still cache resident (rows are independent in both GEMMs).  Measured on
 // MI355X: -3 % end to end (the smaller launches lose more than residency gains), so it is opt-in (UG_FF_CHUNK=1).
-static void ff_pair(Ctx& c, const f16* a, long M, const Lin& f1, const Lin& f2, f16* mid, f16* out, const Epi& e2, const QAct* q = nullptr) {
+static bool ff_pair_fusable(const Ctx& c, long M, const Lin& f1, const Lin& f2, const Epi& e2) {
   const int C4 = f1.out / 2, C = f2.out;
+  return (c.ff_fused & 1) && !c.fp8_linears && ff_fused_supported(C) && f1.in == C && C4 == 4 * C && M >= 32768 && f1.b && !e2.act && !e2.flags &&
+         (!e2.R1 || !e2.ldr1 || e2.ldr1 == C) && (!e2.R2 || !e2.ldr2 || e2.ldr2 == C) && !e2.bias2;
+}
+// pre-norm handed to the fused kernel (ln_ff): LayerNorm parameters + the broadcast row added to the residual stream before it
+struct PreNorm { const f16* g; const f16* b; float eps; const f16* addvec; long rows_per_vec; };
+static void ff_pair(Ctx& c, const f16* a, long M, const Lin& f1, const Lin& f2, f16* mid, f16* out, const Epi& e2, const QAct* q = nullptr,
+                    const PreNorm* pre = nullptr) {
+  const int C4 = f1.out / 2, C = f2.out;
+  UG_REQUIRE(!pre || ff_pair_fusable(c, M, f1, f2, e2), "ff_pair: pre-norm only with the fused kernel");
   // narrow blocks (level 0: C = 320): one fused kernel, the [M, 4C] intermediate never leaves the CU (kernels/ff_fused.hip)
-  if (c.ff_fused && !c.fp8_linears && ff_fused_supported(C) && f1.in == C && C4 == 4 * C && M >= 32768 && f1.b && !e2.act && !e2.flags &&
-      (!e2.R1 || !e2.ldr1 || e2.ldr1 == C) && (!e2.R2 || !e2.ldr2 || e2.ldr2 == C) && !e2.bias2) {
+  if (ff_pair_fusable(c, M, f1, f2, e2)) {
     FFusedP p; memset(&p, 0, sizeof(p));
     p.X = a; p.W1 = f1.w; p.b1 = f1.b; p.W2 = f2.w; p.b2 = f2.b; p.R1 = e2.R1; p.R2 = e2.R2; p.c0 = e2.c0; p.c1 = e2.c1; p.c2 = e2.c2;
     p.Out = out; p.M = (int)M; p.C = C; p.zero = c.zero;
+    if (pre) { p.ln_g = pre->g; p.ln_b = pre->b; p.ln_eps = pre->eps; p.addvec = pre->addvec; p.rows_per_vec = (int)pre->rows_per_vec; }
     char nm[64];
     if (c.prof_on && c.prof_shapes) snprintf(nm, sizeof(nm), "gemm_ff_fused:%ldx%d", M, C); else snprintf(nm, sizeof(nm), "gemm_ff_fused");
     ProfScope ps(c, nm, 2.0 * M * (double)(2 * C4) * C + 2.0 * M * (double)C * C4,
@@ -801,6 +810,21 @@ static void ff_pair(Ctx& c, const f16* a, long M, const Lin& f1, const Lin& f2, 
     if (e.R2) e.R2 += r0 * (e.ldr2 ? e.ldr2 : C);
     linear(c, mid + r0 * C4, m, f2, out + r0 * C, e);
   }
+}
+
+// y = FF(LayerNorm(x')) combined with the residual stream x' = x (+ addvec row): on the narrow level the LayerNorm runs inside the fused
+// feed-forward kernel - neither LayerNorm(x') nor x' are materialised (e2.R1 must be the stream: xout when addvec is given, else x);
+// otherwise the LayerNorm launch (writing t1 and xout) followed by ff_pair.
+static void ln_ff(Ctx& c, const f16* x, long M, const Norm& ln, const f16* addvec, long rows_per_vec, f16* xout, f16* t1,
+                  const Lin& f1, const Lin& f2, f16* mid, f16* out, const Epi& e2, const QAct* q) {
+  if ((c.ff_fused & 2) && ff_pair_fusable(c, M, f1, f2, e2) && ln.g && ln.b && e2.R1 == (addvec ? xout : x) && (!addvec || xout)) {
+    Epi e = e2; e.R1 = x;
+    const PreNorm pre = {ln.g, ln.b, ln.eps, addvec, rows_per_vec};
+    ff_pair(c, x, M, f1, f2, mid, out, e, nullptr, &pre);
+    return;
+  }
+  layernorm(c, x, M, ln, t1, addvec, rows_per_vec, xout, q);
+  ff_pair(c, t1, M, f1, f2, mid, out, e2, q);
 }
 
 static f16* transformer_forward(Ctx& c, const Transformer& tr, const f16* x, int T, int h, int w, int G) {
@@ -834,15 +858,13 @@ static f16* transformer_forward(Ctx& c, const Transformer& tr, const f16* x, int
   f16* h1 = c.ws.get<f16>(M * C);
   { Epi e; e.R1 = h0; linear(c, ao, M, tr.o1, h1, e); }
   f16* h2 = c.ws.get<f16>(M * C);
-  layernorm(c, h1, M, tr.ln3, t1, tr.cross_sp, HW, h2, qp);
   f16* ffm = c.ws.get<f16>(M * 4 * C);
   f16* hs = c.ws.get<f16>(M * C);
-  { Epi e; e.R1 = h2; ff_pair(c, t1, M, tr.ff1, tr.ff2, ffm, hs, e, qp); }
+  { Epi e; e.R1 = h2; ln_ff(c, h1, M, tr.ln3, tr.cross_sp, HW, h2, t1, tr.ff1, tr.ff2, ffm, hs, e, qp); }
   // ---- temporal block (token order kept; only the attention gathers over frames)
   f16* xm = h0;   // h0 is dead
-  layernorm(c, hs, M, tr.ln_in, t1, tr.frame_emb, HW, xm, qp);
   f16* g1 = h1;   // h1 is dead
-  { Epi e; e.R1 = xm; ff_pair(c, t1, M, tr.ffin1, tr.ffin2, ffm, g1, e, qp); }
+  { Epi e; e.R1 = xm; ln_ff(c, hs, M, tr.ln_in, tr.frame_emb, HW, xm, t1, tr.ffin1, tr.ffin2, ffm, g1, e, qp); }
   layernorm(c, g1, M, tr.tln1, t1, nullptr, 1, nullptr, qp);
   linear(c, t1, M, tr.tqkv, qkv, qepi(Epi()));
   {
@@ -854,9 +876,9 @@ static f16* transformer_forward(Ctx& c, const Transformer& tr, const f16* x, int
   f16* g2 = h2;   // h2 is dead
   { Epi e; e.R1 = g1; linear(c, ao, M, tr.to1, g2, e); }
   f16* g3 = xm;   // xm is dead
-  layernorm(c, g2, M, tr.tln3, t1, tr.cross_tm, M, g3, qp);
   f16* mix = g1;
-  { Epi e; e.c0 = 1.f - tr.alpha; e.R1 = g3; e.c1 = 1.f - tr.alpha; e.R2 = hs; e.c2 = tr.alpha; ff_pair(c, t1, M, tr.tff1, tr.tff2, ffm, mix, e, qp); }
+  { Epi e; e.c0 = 1.f - tr.alpha; e.R1 = g3; e.c1 = 1.f - tr.alpha; e.R2 = hs; e.c2 = tr.alpha;
+    ln_ff(c, g2, M, tr.tln3, tr.cross_tm, M, g3, t1, tr.tff1, tr.tff2, ffm, mix, e, qp); }
   { Epi e; e.R1 = x; linear(c, mix, M, tr.proj_out, out, e); }
   c.ws.release(mk);
   return out;

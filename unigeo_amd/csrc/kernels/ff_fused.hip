@@ -17,6 +17,9 @@
 //   (same protocol as gemm_kernel: raw s_barrier, counted vmcnt, LDS-DMA stays in flight across barriers);
 // * swapped MFMA operands + permuted weight rows give every lane 16 (8 in the last piece) contiguous output columns: bias,
 //   GEGLU, residuals and stores are 16-byte vectors.
+// * optional pre-LayerNorm (FFusedP::ln_g): the block's LayerNorm (+ the broadcast cross-attention / frame-embedding row that is
+//   added to the residual stream just before it) is applied to the X tile in LDS, so the normalised [M, C] tensor and the
+//   updated residual stream are never written to / re-read from HBM (one 3-tensor pass per feed-forward saved).
 // LDS: X 16 KiB * C/64 + ring 48 KiB + G 16 KiB = 144 KiB at C = 320; registers: acc2 80 + acc1 32 per lane.
 #include "../common.h"
 #include <algorithm>
@@ -119,6 +122,64 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
     }
     issue_packet(0, 0, 0);
     issue_packet(0, 1, 1);
+
+    if (p.ln_g) {
+      // ---- pre-norm on the LDS tile: 4 threads per token row (2 chunks of 8 channels in each of the KT K tiles), exact two-pass
+      // statistics in fp32 - the values launch_layernorm would have written to HBM and this kernel would have read back.
+      // gamma / beta / the broadcast row are fetched BEFORE the wait for the X tile, so their latency hides behind the tile's.
+      const int row = tid >> 2, q4 = tid & 3;
+      const long mr = (long)m0 + row < p.M ? (long)m0 + row : (long)p.M - 1;
+      const f16* av = p.addvec ? p.addvec + (long)((int)mr / p.rows_per_vec) * C : nullptr;
+      f16x8 ga[KT][2], be[KT][2], ad[KT][2];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          ga[kt][u] = *(const f16x8*)(p.ln_g + kt * 64 + q4 * 16 + u * 8);
+          be[kt][u] = *(const f16x8*)(p.ln_b + kt * 64 + q4 * 16 + u * 8);
+          if (av) ad[kt][u] = *(const f16x8*)(av + kt * 64 + q4 * 16 + u * 8);
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      f16* xr = Xs + row * 64;
+      const int cs[2] = {((q4 * 2) ^ ffswz(row)) * 8, ((q4 * 2 + 1) ^ ffswz(row)) * 8};   // this thread's two chunks of every K tile
+      f16x8 hx[KT][2];
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          hx[kt][u] = *(const f16x8*)(xr + kt * TILE + cs[u]);
+          if (av) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hx[kt][u][e] = (f16)((float)hx[kt][u][e] + (float)ad[kt][u][e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sum += (float)hx[kt][u][e];
+        }
+      sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
+      const float mean = sum / C;
+      float var = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float d = (float)hx[kt][u][e] - mean; var += d * d; }
+      var += __shfl_xor(var, 1); var += __shfl_xor(var, 2);
+      const float rstd = rsqrtf(var / C + p.ln_eps);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          f16x8 y;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] = (f16)(((float)hx[kt][u][e] - mean) * rstd * (float)ga[kt][u][e] + (float)be[kt][u][e]);
+          *(f16x8*)(xr + kt * TILE + cs[u]) = y;
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the first packet's barrier below publishes the normalised tile
+    }
 
     f32x4 acc1[2][4], acc2[NP][2][4];
 #pragma unroll
@@ -236,7 +297,12 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
 #pragma unroll
           for (int q = 0; q < 8; ++q) o[q] = p.c0 * (acc2[pp][i][(e0 + q) >> 2][(e0 + q) & 3] + (float)b[q]);
           if (p.R1) {
-            const f16x8 r = *(const f16x8*)(p.R1 + (long)m * C + n0 + e0);
+            f16x8 r = *(const f16x8*)(p.R1 + (long)m * C + n0 + e0);
+            if (p.ln_g && p.addvec) {   // the residual stream is x' = fp16(X + addvec) (see FFusedP)
+              const f16x8 a = *(const f16x8*)(p.addvec + ((long)m / p.rows_per_vec) * C + n0 + e0);
+#pragma unroll
+              for (int q = 0; q < 8; ++q) r[q] = (f16)((float)r[q] + (float)a[q]);
+            }
 #pragma unroll
             for (int q = 0; q < 8; ++q) o[q] += p.c1 * (float)r[q];
           }
@@ -274,6 +340,7 @@ bool ff_fused_supported(int C) { return C == 64 || C == 128 || C == 192 || C == 
 
 void launch_ff_fused(const FFusedP& p, hipStream_t s) {
   UG_REQUIRE(ff_fused_supported(p.C) && p.M > 0 && p.zero, "ff_fused: C must be a multiple of 64 up to 320");
+  if (p.ln_g) UG_REQUIRE(p.ln_b && (!p.addvec || p.rows_per_vec >= 1) && (!p.addvec || !p.R1 || p.R1 == p.X), "ff_fused pre-norm: beta missing / residual is not the normalised stream");
   switch (p.C / 64) {
     case 1: launch_ff_t<1>(p, s); break;
     case 2: launch_ff_t<2>(p, s); break;
