@@ -69,6 +69,7 @@ void ug_destroy(ug_ctx* x) {
   (void)hipSetDevice(x->c.device);
   (void)hipStreamSynchronize(x->c.stream);
   for (auto& kv : x->c.raw) (void)hipFree(kv.second.dev);
+  for (int i = 0; i < 2; ++i) if (x->c.pin[i]) (void)hipHostFree(x->c.pin[i]);
   x->c.ws.destroy(); x->c.persist.destroy();
   (void)hipStreamDestroy(x->c.stream);
   delete x;

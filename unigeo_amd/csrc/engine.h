@@ -143,11 +143,16 @@ struct Ctx {
   size_t io_mark = 0; bool io_ready = false;
   // parity instrumentation: when set, dc_run copies the latents after every Euler step to this host buffer ([steps][T*h*w*4] f32)
   float* trace_host = nullptr; int trace_steps = 0;
+  // page-locked staging for the host buffers the C ABI hands over (pageable numpy memory): a copy through it is one memcpy + one DMA at
+  // link rate instead of the runtime's chunked staging of a pageable hipMemcpy (slot 0: inputs, 1: outputs); grown on demand
+  void* pin[2] = {nullptr, nullptr}; size_t pin_sz[2] = {0, 0};
   int ff_fused = 3;          // bit 0: fused GEGLU feed-forward kernel for the narrow (C <= 320) transformer blocks (0 = two GEMM launches);
                              // bit 1: its LayerNorm (+ broadcast row added to the residual stream) applied inside that kernel (A/B runs)
   int fp8_linears = 0;       // 1 = run the UNet's eligible linear layers on MX-fp8 MFMAs (BASELINE configs[4]; reduced precision, off by default)
   int vae_encode_fp32 = 1;   // 1 = reference behaviour (float32-grade encoder), 0 = fp16 storage like the decoder
 };
+
+void* pinned(Ctx& c, int slot, size_t bytes);   // page-locked staging buffer of at least `bytes`
 
 // ---- binding ----
 void upload_raw(Ctx& c, const std::string& name, int dtype, const std::vector<long>& shape, const void* host);

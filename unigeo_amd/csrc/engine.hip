@@ -111,6 +111,16 @@ static void run_gemm(Ctx& c, GemmP p, int batch, const char* tag, float alg = 1.
   c.ws.release(mk);
 }
 
+void* pinned(Ctx& c, int slot, size_t bytes) {
+  if (c.pin_sz[slot] < bytes) {
+    if (c.pin[slot]) UG_CHECK(hipHostFree(c.pin[slot]));
+    c.pin[slot] = nullptr; c.pin_sz[slot] = 0;
+    UG_CHECK(hipHostMalloc(&c.pin[slot], bytes, hipHostMallocDefault));
+    c.pin_sz[slot] = bytes;
+  }
+  return c.pin[slot];
+}
+
 static inline long pad256(long x) { return (x + 255) / 256 * 256; }
 // Out[M, lin.out] = A[M, lin.in] W^T (+bias) ...
 static void linear(Ctx& c, const f16* A, long M, const Lin& l, f16* out, const Epi& e = Epi(), long lda = 0,
