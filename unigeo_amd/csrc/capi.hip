@@ -793,6 +793,7 @@ int ug_bench_gemm(ug_ctx* x, int M, int N, int K, int conv, int T, int Hi, int W
     launch_fill_random(Wt, (long)N * K, 3, c.stream); launch_fill_random(b, N, 4, c.stream);
     p.M = M; p.N = N; p.K = K; p.W = Wt; p.ldw = K; p.bias = b; p.c0 = 1.f; p.ldo = N;
     p.zero = c.zero; p.nb_inner = 1;
+    p.kchunk = (conv && kt * k * k > 1 && (C0 + C1) % 64 == 0 && !getenv("UG_NO_KCHUNK")) ? 1 : 0;   // the engine's chunk-major K order (random weights: the layout itself is immaterial)
     p.A0 = As[0]; p.A1 = A1s[0]; p.Out = Os[0];
     if (getenv("UG_BENCH_GEGLU") && !conv && N % 128 == 0) { p.flags |= UG_F_GEGLU; p.ldo = N / 2; }   // A/B aid: GEGLU epilogue
     int cf = cfg, sp = split;

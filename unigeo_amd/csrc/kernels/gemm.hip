@@ -875,16 +875,16 @@ static bool gemm_can_bufa(const GemmP& p, int BK, bool packed) {
 // publishes step i+1 and frees slot i % 3.  Only producers ever have loads in flight in the K loop, so the epilogue's
 // global traffic (consumers) needs no drain logic.  LDS image, W row permutation, MFMA chain order and epilogue are those
 // of gemm_kernel: outputs are bit-identical.
-template <int BN, int WMW, int WNW, bool CONV>
+template <int BM, int BN, int WMW, int WNW, bool CONV>
 __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(const GemmP p) {
-  constexpr int BM = 256, BK = 64, NST = 3;
-  static_assert(BN % 32 == 0 && BN <= 160, "ring of three 256 x BN x 64 slots must fit 160 KiB");
+  constexpr int BK = 64, NST = 3;
+  static_assert(BN % 32 == 0 && (BM == 256 || BM == 192) && BM + BN <= 416, "ring of three BM x BN x 64 slots must fit 160 KiB; BM / 32 A pieces per fetch wave");
   static_assert(WMW * WNW == 8, "eight consumer waves");
   constexpr unsigned SENT = 0x80000000u;
   constexpr int WTM = BM / WMW, WTN = BN / WNW;
   constexpr int MT = WTM / 16, NT = WTN / 16;
   constexpr int WID = 4 * NT;
-  constexpr int LA = 8, LB = BN / 32;                // 1 KiB loads per producer wave per K-step (32 A + BN/8 B pieces / 4 waves)
+  constexpr int LA = BM / 32, LB = BN / 32;          // 1 KiB loads per producer wave per K-step (BM/8 A + BN/8 B pieces / 4 waves)
   constexpr int STAGE = (BM + BN) * BK;
   extern __shared__ __attribute__((aligned(16))) f16 smem[];
 
@@ -1106,18 +1106,18 @@ __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(const GemmP p) {
   }
 }
 
-template <int BN, int WMW, int WNW>
+template <int BN, int WMW, int WNW, int BM = 256>
 static void launch_ws(const GemmP& p, int batch, hipStream_t s) {
-  const int ntiles = cdiv(p.M, 256) * cdiv(p.N, BN);
+  const int ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
 #ifdef UG_GEMM_TRACE
-  const size_t lds = 3 * (256 + BN) * 64 * sizeof(f16) + 2048;
+  const size_t lds = 3 * (BM + BN) * 64 * sizeof(f16) + 2048;
 #else
-  const size_t lds = 3 * (256 + BN) * 64 * sizeof(f16);
+  const size_t lds = 3 * (BM + BN) * 64 * sizeof(f16);
 #endif
   static bool attr = false;
   if (!attr) {
-    UG_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<BN, WMW, WNW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    UG_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<BN, WMW, WNW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    UG_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<BM, BN, WMW, WNW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    UG_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<BM, BN, WMW, WNW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
   const int split = p.splitk > 1 ? p.splitk : 1;
@@ -1125,8 +1125,8 @@ static void launch_ws(const GemmP& p, int batch, hipStream_t s) {
   gx = (gx / 8) * 8;
   gx = std::min(gx, ntiles);
   dim3 grid(gx, split, batch);
-  if (p.conv) hipLaunchKernelGGL((gemm_ws_kernel<BN, WMW, WNW, true>), grid, dim3(768), lds, s, p);
-  else hipLaunchKernelGGL((gemm_ws_kernel<BN, WMW, WNW, false>), grid, dim3(768), lds, s, p);
+  if (p.conv) hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, WMW, WNW, true>), grid, dim3(768), lds, s, p);
+  else hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, WMW, WNW, false>), grid, dim3(768), lds, s, p);
 }
 
 template <int BM, int BN, int NST, int WMW, int WNW>
@@ -1261,6 +1261,12 @@ static void launch_cfg(int cfg, const GemmP& p, int batch, hipStream_t s) {
     case 54: if (gemm_can_bufa(p, 64, true)) launch_ws<128, 4, 2>(p, batch, s); else launch_mode<256, 128, 64, 3, 4, 2>(p, batch, s); break;
     case 60: if (gemm_can_bufa(p, 64, true)) launch_ws<160, 4, 2>(p, batch, s); else launch_mode<256, 64, 64, 2, 4, 2>(p, batch, s); break;   // 256x160: every UNet width is a multiple of 160
     case 34: if (gemm_can_bufa(p, 64, true)) launch_ldr<256, 64, 2, 4, 2>(p, batch, s); else launch_mode<256, 64, 64, 2, 4, 2>(p, batch, s); break;
+    // 192-row tiles: M = 19200 / 4800 (levels 1 / 2 of the clip) are 100 / 25 tiles of 192 rows - with 128 columns the launch is 500 / 250
+    // tiles for 256 CUs (fill 0.98) where 256 rows give 375 / 190 (fill 0.73)
+    case 61: launch_mode<192, 128, 64, 3, 2, 4>(p, batch, s); break;  // 120 KiB, 8 waves, wave tile 96x32
+    case 62: launch_mode<192, 128, 64, 3, 4, 2>(p, batch, s); break;  // 120 KiB, 8 waves, wave tile 48x64 (GEGLU-capable)
+    case 63: if (gemm_can_bufa(p, 64, true)) launch_ws<128, 2, 4, 192>(p, batch, s); else launch_mode<192, 128, 64, 3, 2, 4>(p, batch, s); break;   // producer / consumer form of 61
+    case 64: if (gemm_can_bufa(p, 64, true)) launch_ws<128, 4, 2, 192>(p, batch, s); else launch_mode<192, 128, 64, 3, 4, 2>(p, batch, s); break;   // ... of 62
     default: UG_REQUIRE(false, "unknown / pruned GEMM tile config");
   }
 }
@@ -1332,7 +1338,10 @@ struct TileCand { int id, bm, bn, percu; float dense, conv; bool geglu_ok; };   
 static const TileCand kCands[] = {
     {15, 256, 256, 1, 1200.f, 1190.f, true},  {35, 256, 256, 1, 1190.f, 1200.f, true},  {59, 256, 128, 1, 1143.f, 1154.f, false},
     {54, 256, 128, 1, 1135.f, 1150.f, true},  {19, 256, 128, 1, 1044.f, 1002.f, false}, {0, 128, 128, 2, 890.f, 1025.f, true},
-    {14, 256, 64, 2, 880.f, 883.f, false},    {1, 128, 64, 3, 757.f, 799.f, false},    {12, 64, 64, 5, 456.f, 652.f, false}};
+    {14, 256, 64, 2, 880.f, 883.f, false},    {1, 128, 64, 3, 757.f, 799.f, false},    {12, 64, 64, 5, 456.f, 652.f, false},
+    // 192-row producer / consumer tiles (round 2, tools/tune_192.py): ~0.9 / 0.95 of the 256x128 form's rate per tile, but M = 19200 / 4800 /
+    // 76800 are whole multiples of 192 and the launches fill the chip (500 / 250 tiles instead of 375 / 190)
+    {63, 192, 128, 1, 1030.f, 1120.f, false}, {64, 192, 128, 1, 1020.f, 1110.f, true}};
 
 void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
   const bool geglu = p.flags & UG_F_GEGLU;
@@ -1400,10 +1409,10 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
     }
   } else if (!geglu && !p.conv && p.M <= 512 && p.N >= 2048) {
     cfg = 3;   // wide projection of a few rows: many small tiles beat a handful of large ones (324x3840x1280: 14.4 vs 19.3 us)
-  } else if (plain_epi && p.conv && p.M <= 8192 && nk >= 256 && p.N >= 512) {
-    cfg = 0; split = 4;   // 12x16 level, concatenated 2560-channel input: four K slices fill the last round (880 vs 816 TFLOP/s)
   }
-  if (g_force_cfg >= 0 && !(geglu && g_force_cfg != 0 && g_force_cfg != 4 && g_force_cfg != 8 && g_force_cfg != 15 && g_force_cfg != 35 && g_force_cfg != 54)) cfg = g_force_cfg;
+  // (a former rule - four K slices of the 128x128 tile for the 12x16 level's concatenated 2560-channel convs, 880 TFLOP/s - is gone:
+  // the 192-row tile fills the chip there without split-K, 236 vs 324 us = 1200 TFLOP/s)
+  if (g_force_cfg >= 0 && !(geglu && g_force_cfg != 0 && g_force_cfg != 4 && g_force_cfg != 8 && g_force_cfg != 15 && g_force_cfg != 35 && g_force_cfg != 54 && g_force_cfg != 62 && g_force_cfg != 64)) cfg = g_force_cfg;
   if (g_force_split >= 0) split = plain_epi ? std::max(1, g_force_split) : 1;
   *cfg_out = cfg; *split_out = split;
 }
@@ -1421,6 +1430,7 @@ static int pick_group_m(const GemmP& p, int cfg, int batch, int split) {
     case 14: case 34: bm = 256; bn = 64; percu = 2; break;
     case 15: case 35: bm = 256; bn = 256; break;
     case 60: bm = 256; bn = 160; break;
+    case 61: case 62: case 63: case 64: bm = 192; bn = 128; break;
     default: break;                                                    // 4, 8, 19, 39, 54, 59: 256 x 128
   }
   const int ntm = cdiv(p.M, bm), ntn = cdiv(p.N, bn);
@@ -1451,14 +1461,14 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
   }
   int cfg = p.cfg_p1 - 1, split = p.splitk;
   if (cfg < 0 || split < 1) { int c2, s2; gemm_plan(p, batch, &c2, &s2); if (cfg < 0) cfg = c2; if (split < 1) split = s2; }
-  if (p.flags & UG_F_GEGLU) UG_REQUIRE(cfg == 0 || cfg == 4 || cfg == 8 || cfg == 15 || cfg == 35 || cfg == 54, "GEGLU needs a 64-column wave tile");
+  if (p.flags & UG_F_GEGLU) UG_REQUIRE(cfg == 0 || cfg == 4 || cfg == 8 || cfg == 15 || cfg == 35 || cfg == 54 || cfg == 62 || cfg == 64, "GEGLU needs a 64-column wave tile");
   p.splitk = split;
   if (split > 1) UG_REQUIRE(p.partial != nullptr, "split-K needs a partial buffer");
   p.group_m = pick_group_m(p, cfg, batch, split);
   p.tm_T = p.tm_nb = 0;
   if (p.conv && p.kt > 1 && p.T > 1 && batch == 1 && !(g_knobs & 256)) {   // knob 256: frame-major M walk for temporal convs (A/B)
     int bm = 256;
-    switch (cfg) { case 0: case 1: case 3: bm = 128; break; case 12: bm = 64; break; default: break; }
+    switch (cfg) { case 0: case 1: case 3: bm = 128; break; case 12: bm = 64; break; case 61: case 62: case 63: case 64: bm = 192; break; default: break; }
     const long hw = (long)p.Ho * p.Wo;
     if (hw % bm == 0 && hw / bm >= 1) { p.tm_T = p.T; p.tm_nb = (int)(hw / bm); }
   }
