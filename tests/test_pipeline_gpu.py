@@ -155,6 +155,35 @@ def test_full_size_invariants():
         pipe.engine.close()
 
 
+def test_full_size_unet_fused_feed_forward_paths_agree():
+    """The fused GEGLU feed-forward kernel, its in-kernel LayerNorm and the whole-rounds row split only engage from M = 32768 token rows
+    (level 0 of the 25 x 384 x 512 clip), beyond what the CPU oracle can reach.  The two-GEMM + LayerNorm-launch path they replace is the one
+    every oracle-parity test (tiny and full-architecture configs) exercises, so at full size the UNet must give the same answer either way:
+    * fused kernel (+ row split) vs two launches: BIT-IDENTICAL - same MFMA chain order, same fp16 roundings of the intermediate;
+    * with the LayerNorm inside the kernel the fp32 row sums are taken in another order, which flips the fp16 rounding of ~0.15 % of the
+      normalised values (1.7 % of rows, <= 2.7e-4 at the op level); through the whole UNet that grows to 2.1e-3 of max|v| (measured) -
+      the same size as any other reordering here (VAE-encode chunking: bound 5e-3).  Bound 4e-3."""
+    from unigeo_amd.pipeline import DepthCrafterPipelineHIP
+    pipe = DepthCrafterPipelineHIP.from_random(seed=42, workspace_bytes=40 << 30)
+    try:
+        eng = pipe.engine
+        T, h, w = 25, 48, 64
+        rng = np.random.default_rng(5)
+        x = rng.standard_normal((T, eng.unet_cfg.in_channels, h, w)).astype(np.float32)
+        emb = rng.standard_normal((T, eng.unet_cfg.cross_attention_dim)).astype(np.float32)
+        outs = {}
+        for name, (on, pre) in {"two launches": (False, False), "fused": (True, False), "fused + in-kernel LayerNorm": (True, True)}.items():
+            eng.set_ff_fused(on, prenorm=pre)
+            outs[name] = eng.unet_forward(x, 1.2, emb)
+        eng.set_ff_fused(True, prenorm=True)
+        ref = outs["two launches"]
+        assert np.isfinite(ref).all()
+        assert np.array_equal(outs["fused"], ref), "fused feed-forward (whole rounds fused, thin tail through two GEMMs) is not bit-identical to two launches"
+        assert_close(outs["fused + in-kernel LayerNorm"], ref, 4e-3, "full-size UNet forward, in-kernel LayerNorm vs LayerNorm launches")
+    finally:
+        pipe.engine.close()
+
+
 def test_larger_clip_geometry():
     """BASELINE configs[4] geometry in fp16 (50 frames at 576 x 768, 1 Euler step): T = 50 temporal attention / pooled GroupNorm,
     S = 6912 spatial attention, > 2^31-element-free 32-bit buffer offsets, 12 GiB of activations - finite, in range, reproducible."""

@@ -119,6 +119,7 @@ struct LayerNormP {
   const f16* X; f16* Y; int M, C; float eps;
   const f16* gamma; const f16* beta;
   const f16* addvec; int rows_per_vec; f16* Xout;   // optional
+  long row0;                                        // index of row 0 in the addvec numbering (a row sub-range of a larger tensor)
   // optional MX-fp8 output INSTEAD of Y (fp8 linear path): e4m3 bytes [M][C] + e8m0 block scales, layout of launch_quant_mx8 (C % 128 == 0)
   unsigned char* Y8; unsigned* S8; long ld_s8;
 };

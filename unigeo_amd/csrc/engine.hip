@@ -230,10 +230,10 @@ static QAct qact_alloc(Ctx& c, long M, int K) {
   return q;
 }
 static void layernorm(Ctx& c, const f16* x, long M, const Norm& n, f16* y, const f16* addvec = nullptr,
-                      long rows_per_vec = 1, f16* xout = nullptr, const QAct* q = nullptr) {
+                      long rows_per_vec = 1, f16* xout = nullptr, const QAct* q = nullptr, long row0 = 0) {
   LayerNormP p; memset(&p, 0, sizeof(p));
   p.X = x; p.Y = y; p.M = (int)M; p.C = n.c; p.eps = n.eps; p.gamma = n.g; p.beta = n.b;
-  p.addvec = addvec; p.rows_per_vec = (int)rows_per_vec; p.Xout = xout;
+  p.addvec = addvec; p.rows_per_vec = (int)rows_per_vec; p.Xout = xout; p.row0 = row0;
   if (q) { p.Y8 = q->a8; p.S8 = q->sa; p.ld_s8 = q->ld; }
   ProfScope ps(c, "layernorm", 0, (double)M * n.c * 2.0 * (addvec ? 3.0 : 2.0));
   launch_layernorm(p, c.stream);
@@ -791,12 +791,19 @@ static bool ff_pair_fusable(const Ctx& c, long M, const Lin& f1, const Lin& f2, 
 }
 // pre-norm handed to the fused kernel (ln_ff): LayerNorm parameters + the broadcast row added to the residual stream before it
 struct PreNorm { const f16* g; const f16* b; float eps; const f16* addvec; long rows_per_vec; };
+// The fused kernel runs one 128-row tile per CU at a time: 600 tiles (level 0 of the clip) are 2.34 rounds of 256, and the third round
+// keeps 88 CUs busy while 168 wait.  Rows that would fall into such a thin last round (<= 160 tiles) go through the two-GEMM path
+// instead - the fused kernel then runs whole rounds only (ff_fused_rows).
+static long ff_fused_rows(long M) {
+  const long ntile = (M + 127) / 128, full = ntile / 256 * 256, rem = ntile - full;
+  return (full > 0 && rem > 0 && rem <= 160 && !getenv("UG_FF_NOSPLIT")) ? full * 128 : M;
+}
 static void ff_pair(Ctx& c, const f16* a, long M, const Lin& f1, const Lin& f2, f16* mid, f16* out, const Epi& e2, const QAct* q = nullptr,
-                    const PreNorm* pre = nullptr) {
+                    const PreNorm* pre = nullptr, bool no_fuse = false) {
   const int C4 = f1.out / 2, C = f2.out;
   UG_REQUIRE(!pre || ff_pair_fusable(c, M, f1, f2, e2), "ff_pair: pre-norm only with the fused kernel");
   // narrow blocks (level 0: C = 320): one fused kernel, the [M, 4C] intermediate never leaves the CU (kernels/ff_fused.hip)
-  if (ff_pair_fusable(c, M, f1, f2, e2)) {
+  if (ff_pair_fusable(c, M, f1, f2, e2) && !no_fuse) {
     FFusedP p; memset(&p, 0, sizeof(p));
     p.X = a; p.W1 = f1.w; p.b1 = f1.b; p.W2 = f2.w; p.b2 = f2.b; p.R1 = e2.R1; p.R2 = e2.R2; p.c0 = e2.c0; p.c1 = e2.c1; p.c2 = e2.c2;
     p.Out = out; p.M = (int)M; p.C = C; p.zero = c.zero;
@@ -827,13 +834,30 @@ static void ff_pair(Ctx& c, const f16* a, long M, const Lin& f1, const Lin& f2, 
 // otherwise the LayerNorm launch (writing t1 and xout) followed by ff_pair.
 static void ln_ff(Ctx& c, const f16* x, long M, const Norm& ln, const f16* addvec, long rows_per_vec, f16* xout, f16* t1,
                   const Lin& f1, const Lin& f2, f16* mid, f16* out, const Epi& e2, const QAct* q) {
+  const int C = f2.out;
   if ((c.ff_fused & 2) && ff_pair_fusable(c, M, f1, f2, e2) && ln.g && ln.b && e2.R1 == (addvec ? xout : x) && (!addvec || xout)) {
+    const long M1 = ff_fused_rows(M);     // whole rounds of the fused kernel ...
     Epi e = e2; e.R1 = x;
     const PreNorm pre = {ln.g, ln.b, ln.eps, addvec, rows_per_vec};
-    ff_pair(c, x, M, f1, f2, mid, out, e, nullptr, &pre);
+    ff_pair(c, x, M1, f1, f2, mid, out, e, nullptr, &pre);
+    if (M1 < M) {                          // ... the thin last round's rows: LayerNorm launch + two GEMMs
+      const long o = M1 * C;
+      layernorm(c, x + o, M - M1, ln, t1 + o, addvec, rows_per_vec, addvec ? xout + o : nullptr, nullptr, M1);
+      Epi et = e2; et.R1 = (addvec ? xout : x) + o; if (et.R2) et.R2 += o;
+      ff_pair(c, t1 + o, M - M1, f1, f2, mid, out + o, et, nullptr, nullptr, true);
+    }
     return;
   }
   layernorm(c, x, M, ln, t1, addvec, rows_per_vec, xout, q);
+  if (ff_pair_fusable(c, M, f1, f2, e2)) {
+    const long M1 = ff_fused_rows(M), o = M1 * C;
+    ff_pair(c, t1, M1, f1, f2, mid, out, e2, q);
+    if (M1 < M) {
+      Epi et = e2; if (et.R1) et.R1 += o; if (et.R2) et.R2 += o;
+      ff_pair(c, t1 + o, M - M1, f1, f2, mid, out + o, et, q, nullptr, true);
+    }
+    return;
+  }
   ff_pair(c, t1, M, f1, f2, mid, out, e2, q);
 }
 

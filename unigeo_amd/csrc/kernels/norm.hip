@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const LayerNormP p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[k][e] = (float)h[e];
       if (p.addvec) {
-        const f16x8 a = *(const f16x8*)(p.addvec + (row / p.rows_per_vec) * p.C + v * 8);
+        const f16x8 a = *(const f16x8*)(p.addvec + ((row + p.row0) / p.rows_per_vec) * p.C + v * 8);
         f16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { o[e] = (f16)(x[k][e] + (float)a[e]); x[k][e] = (float)o[e]; }
