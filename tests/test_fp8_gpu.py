@@ -32,6 +32,23 @@ def test_mx8_quantiser_and_gemm(engine, M, K, N):
     report(f"MX-fp8 linear {M}x{N}x{K}: quantisation error vs the fp16-operand product", rel_err(got, A.astype(np.float64) @ W.T.astype(np.float64) + b))
 
 
+@pytest.mark.parametrize("pick", [0, 1, 2, 3])
+def test_mx8_tile_shapes_bitwise_identical(engine, pick):
+    """The four MX tile shapes (256x256, 256x128, 128x128, 192x128) walk K through the same scaled-MFMA chain: outputs must be bit-identical
+    (a ragged M, so the 192-row tile's masked scale fetch and edge rows are exercised)."""
+    rng = np.random.default_rng(77)
+    M, K, N = 2500, 640, 1280
+    A, W, b = h16(rng.standard_normal((M, K))), h16(rng.standard_normal((N, K)) / np.sqrt(K)), h16(rng.standard_normal(N) * 0.1)
+    try:
+        engine.lib.ug_tune_force(101, -1)
+        ref = engine.op_linear_mx8(A, W, bias=b)
+        engine.lib.ug_tune_force(100 + pick, -1)
+        got = engine.op_linear_mx8(A, W, bias=b)
+    finally:
+        engine.lib.ug_tune_force(-1, -1)
+    assert np.array_equal(got, ref), f"MX tile pick {pick}: max diff {np.abs(got - ref).max()}"
+
+
 def test_mx8_geglu_epilogue(engine):
     rng = np.random.default_rng(9)
     M, K, N = 1024, 640, 512

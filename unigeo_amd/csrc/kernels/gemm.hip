@@ -1305,9 +1305,19 @@ void launch_gemm_mx8(const GemmP& p0, hipStream_t s) {
   // largest tile that still gives the 256 CUs ~one workgroup each (profiles/r02_mx8_per_shape.txt: 4800x1280x5120 on 256x256 tiles = 95
   // workgroups ran below the fp16 kernel)
   const long t256 = (long)cdiv(p.M, 256) * cdiv(p.N, 256), t128n = (long)cdiv(p.M, 256) * cdiv(p.N, 128);
-  const int pick = force >= 100 ? force - 100 : (t256 >= 200 ? 0 : t128n >= 200 ? 1 : 2);
+  int pick = t256 >= 200 ? 0 : t128n >= 200 ? 1 : 2;
+  {   // 192-row tile (pick 3) when it fills the last round of the persistent grid markedly better than the pick above (M = 19200 / 4800: 500 /
+      // 250 workgroups instead of 375 / 190 - the fp16 planner's kCands entry 63 / 64, same arithmetic)
+    auto eff = [&](int bm, int bn, int slots, float base) {
+      const long tm = cdiv(p.M, bm), tn = cdiv(p.N, bn), tiles = tm * tn;
+      return base * ((float)p.M / (tm * bm)) * ((float)p.N / (tn * bn)) * ((float)tiles / (cdiv(tiles, (long)slots) * slots));
+    };
+    const float cur = pick == 0 ? eff(256, 256, 256, 1.0f) : pick == 1 ? eff(256, 128, 256, 0.95f) : eff(128, 128, 512, 0.78f);
+    if (eff(192, 128, 256, 0.88f) > 1.04f * cur) pick = 3;
+  }
+  if (force >= 100) pick = force - 100;
   {   // grouped tile walk when the fp8 weights exceed the L2 (same rule as pick_group_m)
-    const int bm = pick == 2 ? 128 : 256, bn = pick == 0 ? 256 : 128, percu = pick == 2 ? 2 : 1;
+    const int bm = pick == 2 ? 128 : pick == 3 ? 192 : 256, bn = pick == 0 ? 256 : 128, percu = pick == 2 ? 2 : 1;
     const int ntm = cdiv(p.M, bm), ntn = cdiv(p.N, bn);
     int g = 1;
     if (!(g_knobs & 32) && (double)p.N * p.K * 2.0 > 3.0 * (1 << 20) && ntm >= 2 && ntn >= 2)
@@ -1317,6 +1327,7 @@ void launch_gemm_mx8(const GemmP& p0, hipStream_t s) {
   switch (pick) {
     case 0: launch_mx<256, 256, 2, 2, 4>(p, s); break;
     case 1: launch_mx<256, 128, 3, 4, 2>(p, s); break;
+    case 3: launch_mx<192, 128, 3, 4, 2>(p, s); break;
     default: launch_mx<128, 128, 2, 2, 2>(p, s); break;
   }
   UG_CHECK(hipGetLastError());
