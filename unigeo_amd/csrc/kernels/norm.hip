@@ -293,7 +293,8 @@ __global__ __launch_bounds__(256) void gn_small(const GroupNormP p) {
 
 static inline void gn_chunks2(int T, int HW, int C, int& nchunk, int& rpc) {
   const GnGeom gg = gn_geom(C);
-  const int want = cdiv(1024, T);                       // chunks per frame we would like
+  static const int total_want = getenv("UG_GN_WANT") ? atoi(getenv("UG_GN_WANT")) : 1024;   // A/B aid
+  const int want = cdiv(total_want, T);                 // chunks per frame we would like
   rpc = cdiv(HW, want);
   const int min_rpc = 4 * gg.rpi;
   if (rpc < min_rpc) rpc = min_rpc;
