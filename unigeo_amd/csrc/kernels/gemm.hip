@@ -1210,9 +1210,10 @@ static void launch_t(const GemmP& p, int batch, hipStream_t s) {
   }
   const int split = p.splitk > 1 ? p.splitk : 1;
   // persistent grid: at most (co-resident workgroups per CU) x 256 CUs, shared with the other grid dimensions
-  int gx = std::max(8, (per_cu * 256) / (split * batch));
-  gx = (gx / 8) * 8;
+  const int cap = std::max(8, (per_cu * 256) / (split * batch));
+  int gx = (cap / 8) * 8;                  // a multiple of 8 keeps the XCD-aware tile walk
   gx = std::min(gx, ntiles);
+  if (gx < ntiles && cap >= ntiles) gx = ntiles;   // ... unless rounding down would push a few tiles into a second round (100 tiles, 5 K slices: 102 -> 96)
   if (gemm_knobs_get() & 1) gx = ntiles;
   dim3 grid(gx, split, batch);
   hipLaunchKernelGGL(kern, grid, dim3(WMW * WNW * 64), lds, s, p);
@@ -1379,14 +1380,14 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
   const bool plain_epi = !geglu && !p.up_phase && !(p.flags & UG_F_OUT_F32) && batch == 1 && (p.N % 8 == 0) && (p.ldo % 8 == 0) &&
                          (!p.R1 || p.ldr1 % 8 == 0) && (!p.R2 || p.ldr2 % 8 == 0);
   // Latency-bound corner (tools/tune_splitk.py): few tiles, long K loops.  Split-K over the 128x128 tile with the largest
-  // factor whose persistent grid (512 / split workgroups, rounded down to a multiple of 8) still holds every tile in one round;
+  // factor whose persistent grid (512 / split workgroups) still holds every tile in one round;
   // mid-length K loops do better with two slices of the 3-stage 128x64 tile.
   if (!geglu && p.M <= 2048 && p.N < 2048) {
     cfg = 3;
     if (plain_epi && p.N >= 128) {
       if (nk >= 128) {
         for (int sp = 8; sp >= 2; --sp)
-          if ((512 / sp) / 8 * 8 >= tiles128 && nk / sp >= 16) { split = sp; cfg = 0; break; }
+          if ((512 / sp) >= tiles128 && nk / sp >= 16) { split = sp; cfg = 0; break; }
       }
       if (split == 1 && nk >= 48) split = 2;
     }
@@ -1397,7 +1398,7 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
       const long t64 = (long)cdiv(p.M, 128) * cdiv(p.N, 64);
       if (p.conv && tiles128 <= 64 && nk >= 64) {
         int sp = (int)std::min<long>(std::min<long>(512 / tiles128, nk / 7), 24);
-        while (sp >= 2 && (512 / sp) / 8 * 8 < tiles128) --sp;     // the persistent grid (a multiple of 8 per K slice) must hold every tile in one round
+        while (sp >= 2 && (512 / sp) < tiles128) --sp;     // the persistent grid must hold every tile in one round
         if (sp >= 2) { cfg = 0; split = sp; }
       } else if (!p.conv && t64 <= 64 && nk >= 16) {
         const int sp = (int)std::min<long>(256 / t64, nk / 5);
@@ -1410,7 +1411,7 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
     // (dense) tiles, K sliced until ~512 are in flight (knob 512 = off; tools/ab_sn.py)
     if (p.conv) {
       int sp = (int)std::min<long>(std::min<long>(512 / tiles128, nk / 8), 8);
-      while (sp >= 2 && (512 / sp) / 8 * 8 < tiles128) --sp;
+      while (sp >= 2 && (512 / sp) < tiles128) --sp;
       cfg = 0; split = std::max(1, sp);
     } else {
       const long t64 = (long)cdiv(p.M, 128) * cdiv(p.N, 64);
