@@ -440,3 +440,27 @@ def test_ff_fused_with_in_kernel_layernorm(engine, M, C, rpv):
     assert_close(got, ref, 2e-3, f"fused LayerNorm + feed-forward {M}x{C}")
     assert_close(got, one, 1e-3, f"in-kernel LayerNorm vs LayerNorm launch + fused feed-forward {M}x{C}")
     assert_close(got, two, 1.5e-3, f"in-kernel LayerNorm vs three launches {M}x{C}")
+
+
+@pytest.mark.parametrize("C1", [0, 320])
+def test_conv_row_split_bitwise_full_size(engine, C1):
+    """3x3 convolution onto 320 channels at the clip's level-0 size (25 x 48 x 64 = 76800 rows): launch_gemm runs the rows of the whole rounds
+    on 256x160 tiles and the remaining 11264 rows as a second launch with a row offset (GemmP::m_off).  Bit-identical to a single launch
+    (knob 1024), and spot-checked against torch."""
+    rng = np.random.default_rng(320 + C1)
+    T, H, W, C0, O = 25, 48, 64, 320, 320
+    x = rnd(rng, T, H, W, C0)
+    x1 = rnd(rng, T, H, W, C1) if C1 else None
+    w = rnd(rng, O, C0 + C1, 1, 3, 3, scale=(9 * (C0 + C1)) ** -0.5)
+    b = rnd(rng, O)
+    try:
+        got = engine.op_conv(x, w, b, x1=x1)
+        engine.lib.ug_tune_force(-100 - 1024, 0)
+        one = engine.op_conv(x, w, b, x1=x1)
+    finally:
+        engine.lib.ug_tune_force(-100, 0)
+    assert np.array_equal(got, one), f"row split changes the result: max diff {np.abs(got - one).max()}"
+    xin = x if x1 is None else np.concatenate([x, x1], -1)
+    for t_ in (0, 21, 24):        # frame 21 straddles the split row (65536 = 21 frames + 1024 rows)
+        ref = conv_ref(xin[t_:t_ + 1], w.reshape(O, C0 + C1, 3, 3), b)
+        assert_close(got[t_:t_ + 1], ref, TOL, f"row-split conv frame {t_}")

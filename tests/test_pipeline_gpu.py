@@ -179,6 +179,16 @@ def test_full_size_unet_fused_feed_forward_paths_agree():
         ref = outs["two launches"]
         assert np.isfinite(ref).all()
         assert np.array_equal(outs["fused"], ref), "fused feed-forward (whole rounds fused, thin tail through two GEMMs) is not bit-identical to two launches"
+        # the level-0 3x3 convolutions run as two row-range launches (whole rounds on 256x160 tiles + the rest; launch_gemm): same MFMA chain
+        # per output element, so switching the split off (knob 1024) must not change a bit - residuals, time-embedding bias and all
+        try:
+            eng.set_ff_fused(False, prenorm=False)
+            eng.lib.ug_tune_force(-100 - 1024, 0)
+            nosplit = eng.unet_forward(x, 1.2, emb)
+        finally:
+            eng.lib.ug_tune_force(-100, 0)
+            eng.set_ff_fused(True, prenorm=True)
+        assert np.array_equal(nosplit, ref), "row-split 3x3 convolutions are not bit-identical to single launches"
         assert_close(outs["fused + in-kernel LayerNorm"], ref, 4e-3, "full-size UNet forward, in-kernel LayerNorm vs LayerNorm launches")
     finally:
         pipe.engine.close()

@@ -73,6 +73,8 @@ struct GemmP {
                          // consecutive K steps, so the activation rows a tile re-reads per tap are still in the XCD's L2 (needs (C0+C1) % 64 == 0)
   int tm_T, tm_nb;       // temporal conv (kt > 1): walk the M tiles frame-fastest - walk index i -> tile (i % tm_T) * tm_nb + i / tm_T, so the tiles of one
                          // pixel block in neighbouring frames (which read each other's rows as taps) run together; 0 = off (needs Ho*Wo % BM == 0)
+  int m_off;             // im2col only, producer / consumer kernel only: this launch covers output rows [m_off, m_off + M) of the convolution
+                         // (Out / R1 / R2 already point at row m_off) - row-split launches, see launch_gemm
   int group_m;           // tile walk: 0 / 1 = row-major, g > 1 = g M-tiles x all N tiles column by column (set by launch_gemm; see tile_coord)
 };
 void launch_gemm_mx8(const GemmP& p, hipStream_t s);   // dense only; C0 = lda and ldw in BYTES (= elements)

@@ -941,7 +941,8 @@ __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(const GemmP p) {
           const bool ok = m < p.M && kt_lo < kt_hi;
           if (CONV) {
             const int hw = p.Ho * p.Wo;
-            const int t = m / hw, rem = m - t * hw;
+            const int mg = m + p.m_off;                   // row of the whole convolution (row-split launches)
+            const int t = mg / hw, rem = mg - t * hw;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             const int y0 = oy * p.stride - p.pad_t, x0 = ox * p.stride - p.pad_l;
             unsigned mk = 0; int bit = 0;
@@ -1131,6 +1132,7 @@ static void launch_ws(const GemmP& p, int batch, hipStream_t s) {
 
 template <int BM, int BN, int NST, int WMW, int WNW>
 static void launch_ldr(const GemmP& p, int batch, hipStream_t s) {
+  UG_REQUIRE(p.m_off == 0, "row-split launches need the producer / consumer kernel");
   const int ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
 #ifdef UG_GEMM_TRACE
   const size_t lds = (size_t)NST * (BM + BN) * 64 * sizeof(f16) + 1024;
@@ -1221,6 +1223,7 @@ static void launch_t(const GemmP& p, int batch, hipStream_t s) {
 
 template <int BM, int BN, int BK, int NST, int WMW, int WNW>
 static void launch_mode(const GemmP& p, int batch, hipStream_t s) {
+  UG_REQUIRE(p.m_off == 0, "row-split launches need the producer / consumer kernel");
   const long lim = (1L << 31) - 64;   // buffer addressing: every byte offset must stay below num_records
   const bool bufw = (long)p.N * p.ldw * 2 < lim && !(gemm_knobs_get() & 4);
   if (p.conv) {
@@ -1466,7 +1469,7 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
   if (p.conv) {
     UG_REQUIRE(p.C0 % 8 == 0 && p.C1 % 8 == 0, "conv channel counts must be multiples of 8");
     UG_REQUIRE(p.K == (p.C0 + p.C1) * p.kt * p.ky * p.kx, "conv K mismatch");
-    UG_REQUIRE(p.M == p.T * p.Ho * p.Wo, "conv M mismatch");
+    UG_REQUIRE(p.M == p.T * p.Ho * p.Wo && p.m_off == 0, "conv M mismatch");
     UG_REQUIRE(p.ups == 1 || p.ups == 2, "ups");
   } else {
     UG_REQUIRE(p.C0 % 8 == 0, "dense lda must be a multiple of 8");
@@ -1475,6 +1478,34 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
   if (cfg < 0 || split < 1) { int c2, s2; gemm_plan(p, batch, &c2, &s2); if (cfg < 0) cfg = c2; if (split < 1) split = s2; }
   if (p.flags & UG_F_GEGLU) UG_REQUIRE(cfg == 0 || cfg == 4 || cfg == 8 || cfg == 15 || cfg == 35 || cfg == 54 || cfg == 62 || cfg == 64, "GEGLU needs a 64-column wave tile");
   p.splitk = split;
+  // Row split for the 3x3 convolutions onto 320 columns (level 0 of the clip): 128-wide tiles waste a sixth of their columns there (320 =
+  // 2.5 x 128) and the 256x160 producer / consumer tile (config 60), which wastes none, leaves 88 of its 600 tiles for a third round.
+  // So: the rows of the WHOLE rounds on 256x160 tiles, the remaining rows as a second launch on whatever tile the planner picks for
+  // them (tools: 76800 rows, 320 -> 320 channels: 127 + 37 us against 185 - 190 us for any single tiling).  Knob 1024 = off.
+  bool planned = p0.cfg_p1 == 0;          // the caller took the planner's choice (run_gemm passes it back explicitly) - not a tuning override
+  if (!planned && g_force_cfg < 0) { int c2, s2; gemm_plan(p0, batch, &c2, &s2); planned = (c2 == cfg && s2 == split); }
+  if (planned && p.conv && p.kt == 1 && p.ky == 3 && p.kx == 3 && p.N % 160 == 0 && p.N <= 320 && split == 1 && batch == 1 && !p.up_phase && !(p.flags & (UG_F_OUT_F32 | UG_F_GEGLU)) &&
+      g_force_cfg < 0 && !(g_knobs & 1024) && gemm_can_bufa(p, 64, true)) {
+    const long ntn = p.N / 160, tiles = (long)cdiv(p.M, 256) * ntn, whole = tiles / 256 * 256, rem = tiles - whole;
+    if (whole > 0 && rem > 0 && rem * 2 <= 256) {
+      const int M1 = (int)(whole / ntn) * 256;
+      GemmP a = p; a.M = M1; a.cfg_p1 = 61;                     // config 60 (+ 1)
+      GemmP b = p0; b.M = p.M - M1; b.m_off = M1; b.Out = (void*)((f16*)p.Out + (long)M1 * p.ldo);
+      if (p.flags & UG_F_NOXCD) b.flags |= UG_F_NOXCD;
+      if (b.R1) b.R1 += (long)M1 * p.ldr1;
+      if (b.R2) b.R2 += (long)M1 * p.ldr2;
+      int cb, sb; gemm_plan(b, 1, &cb, &sb);
+      if (cb != 59 && cb != 60 && cb != 63 && cb != 64 && cb != 54) cb = 63;
+      b.cfg_p1 = cb + 1; b.splitk = 1;
+      a.splitk = 1;
+      a.group_m = pick_group_m(a, 60, 1, 1); a.tm_T = a.tm_nb = 0;
+      launch_cfg(60, a, 1, s);
+      b.group_m = pick_group_m(b, cb, 1, 1); b.tm_T = b.tm_nb = 0;
+      launch_cfg(cb, b, 1, s);
+      UG_CHECK(hipGetLastError());
+      return;
+    }
+  }
   if (split > 1) UG_REQUIRE(p.partial != nullptr, "split-K needs a partial buffer");
   p.group_m = pick_group_m(p, cfg, batch, split);
   p.tm_T = p.tm_nb = 0;
