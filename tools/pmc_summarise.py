@@ -19,8 +19,11 @@ json.dump(out, open("gpurun_out/pmc_summary.json", "w"))
 if "FETCH_SIZE" in out and "WRITE_SIZE" in out and out["FETCH_SIZE"]["dispatch_rows"]:
     ev = json.load(open("gpurun_out/pmc_events.json")) if os.path.exists("gpurun_out/pmc_events.json") else {}
     n = out["FETCH_SIZE"]["dispatch_rows"]
-    rd = out["FETCH_SIZE"]["sum"] * 1024 * 2 / n          # counters are in KB; FETCH doubled (gfx950 note)
-    wr = out["WRITE_SIZE"]["sum"] * 1024 / out["WRITE_SIZE"]["dispatch_rows"]
+    # a "launch" is one GEMM launch of the engine (one HIP-event bracket of bench.py's roofline): the row-split 3x3 convolutions are TWO
+    # dispatches each, so the divisor is the engine's launch count, not the dispatch count
+    nl = ev.get("gemm_launches") or n
+    rd = out["FETCH_SIZE"]["sum"] * 1024 * 2 / nl         # counters are in KB; FETCH doubled (gfx950 note)
+    wr = out["WRITE_SIZE"]["sum"] * 1024 / nl
     alg = ev.get("algorithmic_bytes_per_launch")
     json.dump({"workload": f"tools/one_clip.py {ev.get('denoise_steps')} (25x384x512 clip, CLIP + VAE enc/dec + that many Euler steps), GEMM-family dispatches only",
                "denoise_steps": ev.get("denoise_steps"), "dispatches": n, "hip_event_gemm_launches": ev.get("gemm_launches"),
