@@ -796,6 +796,7 @@ int ug_bench_gemm(ug_ctx* x, int M, int N, int K, int conv, int T, int Hi, int W
     p.kchunk = (conv && kt * k * k > 1 && (C0 + C1) % 64 == 0 && !getenv("UG_NO_KCHUNK")) ? 1 : 0;   // the engine's chunk-major K order (random weights: the layout itself is immaterial)
     p.A0 = As[0]; p.A1 = A1s[0]; p.Out = Os[0];
     if (getenv("UG_BENCH_GEGLU") && !conv && N % 128 == 0) { p.flags |= UG_F_GEGLU; p.ldo = N / 2; }   // A/B aid: GEGLU epilogue
+    if (getenv("UG_BENCH_R1")) { p.R1 = Os[nbuf - 1]; p.ldr1 = N; p.c1 = 1.f; }                          // A/B aid: a residual operand in the epilogue
     int cf = cfg, sp = split;
     if (cf < 0 || sp < 1) { int c2, s2; gemm_plan(p, 1, &c2, &s2); if (cf < 0) cf = c2; if (sp < 1) sp = s2; }
     p.cfg_p1 = cf + 1; p.splitk = sp;
