@@ -59,7 +59,7 @@ __device__ __forceinline__ void pv_block(const f16* vt, int kb, int lane, const 
 }
 
 #define FA_KV 64
-#define FA_NST 3   // KV ring depth
+// KV ring depth: template parameter FA_NST of flash_attn64_kernel (3; the occupancy-4 A/B variant uses 2)
 #define FA_QB 1    // 32-query blocks per wave (2 was measured: fewer L2->LDS bytes but occupancy 3 -> 2 waves/SIMD, net -5 %)
 
 // One KV tile of 64 keys for a wave's FA_QB x 32 query rows.  MASK is only instantiated for the ragged last tile,
@@ -222,8 +222,8 @@ void flash_set_variant(int v) { g_fa_wide = v; }
 // The grid is 1-D: workgroup L runs on XCD L % 8, and each XCD has its own L2.  With the natural order the query blocks of one
 // (frame, head) are dealt round-robin to all 8 XCDs, so every L2 fetches that head's K / V for itself; the permutation below hands each
 // XCD a contiguous run of (frame, head, query-block) triples instead, so the K / V of a head are fetched into ONE L2.
-template <bool WIDE>
-__global__ __launch_bounds__(256, 3) void flash_attn64_kernel(const FlashP p, int nqb, int xcd_group) {
+template <bool WIDE, int FA_NST = 3, int OCC = 3>
+__global__ __launch_bounds__(256, OCC) void flash_attn64_kernel(const FlashP p, int nqb, int xcd_group) {
   __shared__ __attribute__((aligned(16))) f16 lds[FA_NST * 2 * FA_KV * 64];  // [slot][K|V][64][64]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -345,8 +345,11 @@ void launch_flash_attn64(const FlashP& p, hipStream_t s) {
   const long total = (long)nqb * p.H * p.B;
   UG_REQUIRE(total < (1L << 31), "flash attention grid");
   const int xcd_group = (total % 8 == 0 && (g_fa_wide & 2)) ? 1 : 0;
-  if (g_fa_wide & 1) hipLaunchKernelGGL(flash_attn64_kernel<true>, dim3((unsigned)total), dim3(256), 0, s, p, nqb, xcd_group);
-  else hipLaunchKernelGGL(flash_attn64_kernel<false>, dim3((unsigned)total), dim3(256), 0, s, p, nqb, xcd_group);
+  if (g_fa_wide & 4) {   // A/B: 2-slot ring (32 KiB) and 4 workgroups per CU
+    if (g_fa_wide & 1) hipLaunchKernelGGL((flash_attn64_kernel<true, 2, 4>), dim3((unsigned)total), dim3(256), 0, s, p, nqb, xcd_group);
+    else hipLaunchKernelGGL((flash_attn64_kernel<false, 2, 4>), dim3((unsigned)total), dim3(256), 0, s, p, nqb, xcd_group);
+  } else if (g_fa_wide & 1) hipLaunchKernelGGL((flash_attn64_kernel<true>), dim3((unsigned)total), dim3(256), 0, s, p, nqb, xcd_group);
+  else hipLaunchKernelGGL((flash_attn64_kernel<false>), dim3((unsigned)total), dim3(256), 0, s, p, nqb, xcd_group);
   UG_CHECK(hipGetLastError());
 }
 
