@@ -216,7 +216,7 @@ __device__ __forceinline__ void fa_tile_wide(const f16* kt, const f16* vt, const
       }
 }
 
-static int g_fa_wide = 3;   // A/B knob (ug_tune_flash): bit 0 = fa_tile_wide, bit 1 = XCD-grouped workgroup order
+static int g_fa_wide = 7;   // A/B knob (ug_tune_flash): bit 0 = fa_tile_wide, bit 1 = XCD-grouped workgroup order, bit 2 = 2-slot ring + 4 workgroups per CU
 void flash_set_variant(int v) { g_fa_wide = v; }
 
 // The grid is 1-D: workgroup L runs on XCD L % 8, and each XCD has its own L2.  With the natural order the query blocks of one
