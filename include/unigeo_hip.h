@@ -97,6 +97,12 @@ int ug_dc_get_outputs(ug_ctx* ctx, float* frames_out, float* depth_out, float* n
  * fp32 residual stream / GroupNorm / softmax, GEMMs on fp16 hi/lo activation pairs against the (fp16-valued) weights, which is
  * exact to fp32 rounding.  on = 0: fp16 storage with fp32 accumulation, like the decoder (faster, ~1e-3 off the fp32 result). */
 int ug_set_vae_encode_fp32(ug_ctx* ctx, int on);
+/* Independent sub-graphs of one pipeline call in flight at a time (default 3; 1 = strictly one kernel after another).  The reference's
+ * pipeline encodes / decodes the clip in chunks of `decode_chunk_size` frames one after the other and computes the CLIP embeddings before
+ * them (the calls inside pipeline(...) at model/depthcrafter.py:80-90); those chunks do not depend on each other, so the engine issues them on
+ * separate HIP streams - one chunk's HBM-bound passes overlap another's MFMA-bound ones.  Same kernels, same launch parameters:
+ * outputs are bit-identical for every setting. */
+int ug_set_concurrency(ug_ctx* ctx, int lanes);
 /* Tuning / parity aids for the fused GEGLU feed-forward kernel of the narrow transformer blocks (kernels/ff_fused.hip; the reference's
  * FeedForward module inside the un-vendored UNet): ug_set_ff_fused(0) falls back to two GEMM launches; ug_op_ff evaluates
  * c0 * (GEGLU(X W1^T + b1) W2^T + b2) + c1 * R1 on [M, C] with either implementation (W1 [8C][C], b1 [8C], W2 [C][4C] in diffusers order). */
@@ -192,7 +198,7 @@ int ug_bench_groupnorm(ug_ctx* ctx, int C0, int C1, int T, int HW, int temporal,
 int ug_bench_gemm(ug_ctx* ctx, int M, int N, int K, int conv, int T, int Hi, int Wi, int C0, int C1, int kt, int k,
                   int stride, int ups, int cfg, int split, int iters, float* ms_out);
 int ug_tune_force(int cfg, int split);
-int ug_tune_flash(int variant);   /* A/B knob: body of the flash-attention KV tile (0 = per-32-key softmax steps, 1 = one step per 64 keys) */
+int ug_tune_flash(int variant);   /* test aid: process default of the flash-attention variant mask (bit 0: one softmax step per 64 keys, bit 1: XCD-grouped workgroup order, bit 2: 2-slot ring + 4 workgroups per CU; default 7).  ug_bench_flash passes its variant with the launch and leaves this alone. */
 
 /* HIP-event profiling of everything launched between begin and end; end returns a JSON
  * object {kernel_family: {ms, calls, flops, bytes}} valid until the next call on ctx. */

@@ -1,0 +1,110 @@
+"""BASELINE configs[1] at FULL size against the CPU oracle: one 25-frame 384x512 clip, 25 Karras-Euler steps, the real 1.52 B-parameter
+architecture - the exact workload bench.py times (from_random(seed=42) weights, synthetic_clip(seed=1234) frames, make_noise(seed=0)).
+
+The oracle's answer was computed once in the build container (tests/golden/make_fullsize_golden.py, ~1 h of CPU) and is committed as
+tests/golden/fullsize_25step_golden.npz: final latents, per-step latent statistics, latents after steps 1 / 13 / 24, the first UNet
+evaluation, the float32 VAE-encoder output, the CLIP embeddings, decoded frames (every 4th pixel + three whole frames), the wrapper's
+depth and the north-star metrics of the oracle's depth / normals against a synthetic ground truth.
+
+This is the first ORACLE comparison of the code paths that only engage at M >= 32768 rows (fused GEGLU feed-forward with its in-kernel
+LayerNorm, 192-row tiles, row-split level-0 convolutions, frame-fastest temporal walks) and of the multi-stream chunk scheduling.
+Reference call: /root/reference/model/depthcrafter.py:80-97.  Bounds = the trajectory bounds of tests/test_trajectory_gpu.py.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from util import report
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_25step_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def run():
+    from unigeo_amd.model.depthcrafter import DepthCrafter
+    from unigeo_amd.pipeline import DepthCrafterPipelineHIP, make_noise
+    from unigeo_amd.synthetic import synthetic_clip
+    g = dict(np.load(GOLD))
+    T, H, W, steps = (int(x) for x in g["geometry"])
+    assert (T, H, W, steps) == (25, 384, 512, 25) and tuple(g["seeds"]) == (42, 1234, 0)
+    pipe = DepthCrafterPipelineHIP.from_random(seed=42, workspace_bytes=40 << 30)
+    try:
+        eng = pipe.engine
+        sample = synthetic_clip(T, H, W, seed=1234)
+        frames = DepthCrafter.prepare_input(None, sample)
+        nl, na = make_noise(T, H, W, seed=0)
+        K = np.stack(sample["intrinsics"], 0)
+        eng.set_inputs(frames, nl, na, K)
+        tr = eng.run_traced(steps, 8, with_normals=True)                      # [steps,T,4,h,w] latents after every Euler step
+        fr, depth, normals = eng.get_outputs(frames=True, depth=True, normals=True)
+        eng.run(steps, 8, with_normals=True)                                   # again, untraced, chunks on concurrent lanes: must not change a bit
+        fr2, depth2, _ = eng.get_outputs(frames=True, depth=True, normals=False)
+        cond = eng.vae_encode((frames[:2] * 2 - 1 + 0.02 * na[:2].transpose(0, 2, 3, 1)).astype(np.float16).astype(np.float32))
+        emb = eng.clip_embed(frames[:4])
+    finally:
+        pipe.engine.close()
+    return dict(g=g, tr=tr, fr=fr, depth=depth, normals=normals, fr2=fr2, depth2=depth2, cond=cond, emb=emb, K=K, na=na)
+
+
+def test_conditioning_stages(run):
+    g = run["g"]
+    e_clip = float(np.abs(run["emb"] - g["clip_emb"][:4]).max() / np.abs(g["clip_emb"]).max())
+    e_cond = float(np.abs(run["cond"] - g["cond_latents"][:2]).max() / np.abs(g["cond_latents"]).max())
+    report("fullsize.clip_emb_rel_err", e_clip); report("fullsize.cond_latents_rel_err", e_cond)
+    assert e_clip < 2.5e-3 and e_cond < 3e-3, (e_clip, e_cond)     # cond: the stand-alone encode call rounds its input once more than the pipeline does
+
+
+def test_25_step_trajectory_against_the_oracle(run):
+    g, tr = run["g"], run["tr"].astype(np.float64)
+    assert tr.shape == (25, 25, 4, 48, 64) and np.isfinite(tr).all()
+    amax = np.abs(tr).max(axis=(1, 2, 3, 4)); l2 = np.sqrt((tr ** 2).sum(axis=(1, 2, 3, 4))); mean = tr.mean(axis=(1, 2, 3, 4))
+    e_l2 = np.abs(l2 - g["latent_l2"]) / g["latent_l2"]
+    e_mean = np.abs(mean - g["latent_mean"]) / g["latent_absmax"]
+    e_amax = np.abs(amax - g["latent_absmax"]) / g["latent_absmax"]
+    report("fullsize.latent_l2_rel_err_max_over_steps", e_l2.max(), per_step=[float(x) for x in e_l2])
+    report("fullsize.latent_mean_err_over_absmax_max_over_steps", e_mean.max())
+    report("fullsize.latent_absmax_rel_err_max_over_steps", e_amax.max())
+    per = []
+    for j, (i, sc) in enumerate(zip(g["latents_step_index"], g["latents_step_scale"])):
+        ref = g["latents_step"][j].astype(np.float64) * sc                    # stored as fp16 of latents / absmax: 5e-4 of the scale
+        per.append(float(np.abs(tr[int(i)] - ref).max() / sc))
+        report(f"fullsize.latent_rel_err_after_step_{int(i) + 1}", per[-1])
+    e_fin = float(np.abs(tr[-1] - g["latents_final"]).max() / np.abs(g["latents_final"]).max())
+    report("fullsize.latent_rel_err_final", e_fin)
+    assert e_l2.max() < 1e-3 and e_mean.max() < 1e-3 and e_amax.max() < 8e-3
+    assert max(per) < 4.5e-3 and e_fin < 4e-3, (per, e_fin)
+
+
+def test_frames_depth_and_metrics(run):
+    from oracle.geometry import prepare_output
+    from unigeo_amd.harness import depth_evaluation, normal_evaluation
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(os.path.dirname(GOLD), "make_fullsize_golden.py"))
+    mk = importlib.util.module_from_spec(spec); spec.loader.exec_module(mk)
+    g, fr, depth = run["g"], run["fr"], run["depth"]
+    assert fr.shape == (25, 384, 512, 3) and fr.min() >= 0 and fr.max() <= 1
+    assert np.array_equal(run["fr2"], fr) and np.array_equal(run["depth2"], depth), "traced (serial) and lane-scheduled runs differ"
+    e_sub = float(np.abs(fr[:, ::4, ::4] - g["frames_sub"].astype(np.float32)).max())
+    e_full = float(np.abs(fr[g["frames_full_index"]] - g["frames_full"].astype(np.float32)).max())
+    e_mean = float(np.abs(fr[:, ::4, ::4] - g["frames_sub"].astype(np.float32)).mean())
+    report("fullsize.frames_abs_err_subsampled", e_sub); report("fullsize.frames_abs_err_three_full_frames", e_full); report("fullsize.frames_mean_abs_err", e_mean)
+    chm = fr.sum(-1) / 3
+    report("fullsize.frames_min_err", abs(float(chm.min()) - float(g["frames_min"]))); report("fullsize.frames_max_err", abs(float(chm.max()) - float(g["frames_max"])))
+    e_depth = float((np.abs(depth[:, ::4, ::4] - g["depth_sub"]) / g["depth_sub"]).max())
+    report("fullsize.depth_rel_err_subsampled", e_depth)
+    assert e_sub < 7e-3 + 5e-4 and e_full < 7e-3 + 5e-4, (e_sub, e_full)      # + the fp16 storage of the fixture
+    # north_star: Abs Rel / normal mean of the HIP pipeline's depth + normals equal to the oracle's (stored) to 3 s.f.
+    T, H, W = depth.shape
+    gt_d = mk.synthetic_gt(T, H, W)
+    _, gt_n = prepare_output(list(gt_d), list(run["K"]))
+    mask = np.ones((T, H, W), bool); mask[:, :3] = False
+    md = depth_evaluation(depth, gt_d, custom_mask=mask, align_with_lstsq=True)[0]
+    mn = normal_evaluation(run["normals"], gt_n.numpy(), custom_mask=mask)
+    want = dict(zip([str(x) for x in g["metric_names"]], g["metrics"]))
+    for k, v in (("Abs Rel", md["Abs Rel"]), ("delta < 1.25", md["delta < 1.25"]), ("normal mean", mn["normal mean"]), ("normal median", mn["normal median"])):
+        report(f"fullsize.metric[{k}].hip", v); report(f"fullsize.metric[{k}].oracle", want[k])
+    sf3 = lambda x: float(f"{x:.3g}")
+    assert md["Abs Rel"] == pytest.approx(want["Abs Rel"], rel=5e-4) and mn["normal mean"] == pytest.approx(want["normal mean"], rel=5e-4)
+    assert sf3(md["Abs Rel"]) == pytest.approx(sf3(want["Abs Rel"]), rel=2e-3) and sf3(mn["normal mean"]) == pytest.approx(sf3(want["normal mean"]), rel=2e-3)

@@ -172,7 +172,8 @@ def test_flash_attention_online_softmax_rescale(engine):
     assert_close(engine.op_flash_attn(qkv, B, H, S), attn_ref(qkv, B, S, H, 64), TOL, "flash rescale")
 
 
-@pytest.mark.parametrize("T,HW,H", [(25, 12, 2), (5, 7, 1), (1, 4, 1), (32, 3, 2), (33, 5, 1), (50, 9, 2), (64, 4, 1)])
+@pytest.mark.parametrize("T,HW,H", [(25, 12, 2), (5, 7, 1), (1, 4, 1), (32, 3, 2), (33, 5, 1), (50, 9, 2), (64, 4, 1),
+                                    (65, 5, 1), (96, 3, 2), (97, 4, 1), (128, 3, 2)])   # NB = 3 (65..96 frames) and NB = 4 (97..128, 64 KiB of static LDS)
 def test_temporal_attention(engine, T, HW, H):
     rng = np.random.default_rng(T)
     qkv = rnd(rng, T * HW, 3 * H * 64)

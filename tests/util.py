@@ -34,6 +34,33 @@ def t(a):
     return torch.from_numpy(np.asarray(a, dtype=np.float32))
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def fp16_storage(*modules):
+    """fp16-storage emulation of an fp16 run of the CPU oracle: every leaf module's output (convolution, linear, norm) is rounded to fp16
+    while the arithmetic inside it stays fp32 - what an fp16 GPU run does (fp16 tensors, fp32 accumulators).  torch-CPU's own fp16 kernels
+    are far too slow for the full architecture; on the tiny configuration the emulation is checked against a real ``.half()`` run
+    (tests/test_stages_gpu.py).  north_star's 1e-3 is stated against an fp16 reference run: HIP vs THIS is the quantity it bounds."""
+    hooks = []
+
+    def rnd(_m, _inp, out):
+        if torch.is_tensor(out) and out.is_floating_point():
+            return out.half().float()
+        return None
+
+    for mod in modules:
+        for m in mod.modules():
+            if not list(m.children()):
+                hooks.append(m.register_forward_hook(rnd))
+    try:
+        yield
+    finally:
+        for h in hooks:
+            h.remove()
+
+
 def report(name, value, **extra):
     """Print a measured parity number and append it to gpurun_out/parity_measured.jsonl (copied to profiles/ per round)
     so that every tolerance in tests/ can be read next to the value that was actually measured on the GPU."""

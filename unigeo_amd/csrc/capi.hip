@@ -71,6 +71,8 @@ void ug_destroy(ug_ctx* x) {
   for (auto& kv : x->c.raw) (void)hipFree(kv.second.dev);
   for (int i = 0; i < 2; ++i) if (x->c.pin[i]) (void)hipHostFree(x->c.pin[i]);
   x->c.ws.destroy(); x->c.persist.destroy();
+  for (auto& l : x->c.lanes) { (void)hipStreamSynchronize(l.stream); (void)hipEventDestroy(l.done); (void)hipStreamDestroy(l.stream); }
+  if (x->c.fork_ev) (void)hipEventDestroy(x->c.fork_ev);
   (void)hipStreamDestroy(x->c.stream);
   delete x;
 }
@@ -130,6 +132,11 @@ int ug_set_ff_fused(ug_ctx* x, int on) {
 int ug_set_fp8_linears(ug_ctx* x, int on) {
   if (!x) return -1;
   x->c.fp8_linears = on ? 1 : 0;
+  return 0;
+}
+int ug_set_concurrency(ug_ctx* x, int lanes) {
+  if (!x) return -1;
+  x->c.concurrency = std::max(1, std::min(lanes, 8));
   return 0;
 }
 int ug_set_vae_encode_fp32(ug_ctx* x, int on) {
@@ -556,7 +563,7 @@ int ug_bench_flash(ug_ctx* x, int B, int H, int S, int variant, int iters, float
     f16* qkv = c.ws.get<f16>(M * 3 * C); f16* o = c.ws.get<f16>(M * C);
     launch_fill_random(qkv, M * 3 * C, 7, c.stream);
     FlashP p; p.Q = qkv; p.K = qkv + C; p.V = qkv + 2 * C; p.ldq = p.ldk = p.ldv = 3 * C; p.O = o; p.ldo = C; p.B = B; p.H = H; p.S = S; p.scale = 0.125f;
-    flash_set_variant(variant);
+    p.variant = variant;     // passed with the launch: the process default (and every other launch) is untouched
     launch_flash_attn64(p, c.stream); launch_flash_attn64(p, c.stream);
     hipEvent_t e0, e1; UG_CHECK(hipEventCreate(&e0)); UG_CHECK(hipEventCreate(&e1));
     UG_CHECK(hipEventRecord(e0, c.stream));
@@ -565,7 +572,6 @@ int ug_bench_flash(ug_ctx* x, int B, int H, int S, int variant, int iters, float
     UG_CHECK(hipEventSynchronize(e1));
     float ms = 0.f; UG_CHECK(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    flash_set_variant(0);
     *us_out = ms * 1000.f / iters;
   });
 }

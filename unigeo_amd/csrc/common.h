@@ -32,6 +32,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
   } while (0)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+// hipFuncSetAttribute is per device: the "already raised the dynamic-LDS limit" caches are indexed by the current device
+static inline int ug_dev_slot() { int d = 0; (void)hipGetDevice(&d); return d & 31; }
 
 // ---------------------------------------------------------------------------------------
 // GEMM / implicit-GEMM convolution  (kernels/gemm.hip)
@@ -139,9 +141,11 @@ struct FlashP {
   f16* O; long ldo;
   int B, H, S; float scale;
   int Sk = 0; int kv_shared = 0;
+  int variant = -1;   // A/B aid (tools/bench_flash.py): -1 = the process default (7), else a bit mask - 1 = one softmax step per 64 keys, 2 = XCD-grouped
+                      // workgroup order, 4 = 2-slot K/V ring + 4 workgroups per CU
 };
 void launch_flash_attn64(const FlashP& p, hipStream_t s);
-void flash_set_variant(int v);   // tuning aid: A/B variants of the KV-tile body (tools/bench_flash.py)
+void flash_set_variant(int v);   // test aid: the process default of FlashP::variant (ug_tune_flash)
 
 // Temporal self-attention: for every pixel p and head h, sequence over the T frames
 // (row of frame t = t*HW + p), head_dim 64, T <= 128 (BASELINE config 5 uses 50-frame clips; upstream DepthCrafter's default window is 110 frames).

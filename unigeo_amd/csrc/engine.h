@@ -24,8 +24,14 @@ class Arena {
   void release(size_t m) { off_ = m; }
   size_t peak() const { return peak_; }
   size_t capacity() const { return cap_; }
+  // a sub-arena over memory carved from another arena (lanes, see run_lanes): never destroy()ed, the owner releases its mark instead
+  void view(void* base, size_t bytes) { base_ = (char*)base; cap_ = bytes; off_ = 0; peak_ = 0; hi_ = 0; }
+  // high-water mark since the last reset_high(): how much a graph function needed on top of the offset it started from
+  void reset_high() { hi_ = off_; }
+  size_t high() const { return hi_; }
+  void note_peak(size_t p) { if (p > peak_) peak_ = p; }
  private:
-  char* base_ = nullptr; size_t cap_ = 0, off_ = 0, peak_ = 0;
+  char* base_ = nullptr; size_t cap_ = 0, off_ = 0, peak_ = 0, hi_ = 0;
 };
 
 struct Lin { const f16* w = nullptr; const f16* b = nullptr; int in = 0, out = 0;
@@ -125,6 +131,11 @@ struct SN {
 
 struct ProfRec { std::string name; double flops, bytes; hipEvent_t e0, e1; };
 
+// A lane = one extra HIP stream + a private slice of the activation arena.  Independent sub-graphs of one clip (the 8-frame chunks of the VAE
+// encoder / decoder, the CLIP tower) are issued on different lanes so that one chunk's HBM-bound passes (GroupNorm, fp32 adds, splits) and
+// the thin last rounds of its persistent GEMMs overlap another chunk's MFMA-bound kernels (engine.hip: run_lanes).
+struct Lane { hipStream_t stream = nullptr; hipEvent_t done = nullptr; };
+
 struct Ctx {
   int device = 0; hipStream_t stream = nullptr;
   Arena ws;        // transient activations
@@ -150,6 +161,10 @@ struct Ctx {
                              // bit 1: its LayerNorm (+ broadcast row added to the residual stream) applied inside that kernel (A/B runs)
   int fp8_linears = 0;       // 1 = run the UNet's eligible linear layers on MX-fp8 MFMAs (BASELINE configs[4]; reduced precision, off by default)
   int vae_encode_fp32 = 1;   // 1 = reference behaviour (float32-grade encoder), 0 = fp16 storage like the decoder
+  // lanes (run_lanes): streams are created on first use; lane_need remembers the arena bytes a task kind needed when it first ran serially
+  std::vector<Lane> lanes; hipEvent_t fork_ev = nullptr;
+  int concurrency = 3;       // independent sub-graphs in flight (1 = everything on the one stream, in order); outputs are bit-identical
+  std::map<std::string, size_t> lane_need;
 };
 
 void* pinned(Ctx& c, int slot, size_t bytes);   // page-locked staging buffer of at least `bytes`

@@ -26,7 +26,106 @@ void* Arena::alloc(size_t bytes) {
   void* p = base_ + off_;
   off_ += a;
   if (off_ > peak_) peak_ = off_;
+  if (off_ > hi_) hi_ = off_;
   return p;
+}
+
+// A pipeline call's hold on the activation arena: whatever way the call ends (a failed UG_REQUIRE, "device arena exhausted", a HIP error), the
+// stream(s) are drained, the arena returns to where the call found it and the per-run caches that point into it are forgotten - a later call
+// on the same context starts from a clean arena instead of failing with "arena exhausted" for ever.
+struct RunGuard {
+  Ctx& c; size_t mk;
+  explicit RunGuard(Ctx& c_) : c(c_), mk(c_.ws.mark()) {}
+  ~RunGuard() {
+    (void)hipStreamSynchronize(c.stream);
+    for (auto& l : c.lanes) (void)hipStreamSynchronize(l.stream);
+    c.ws.release(mk);
+    c.unet.tproj = nullptr; c.unet.tproj_steps = 0;
+    auto forget = [](Transformer& t) { t.frame_emb = nullptr; t.frame_emb_T = 0; t.cross_sp = nullptr; t.cross_tm = nullptr; };
+    for (auto& d : c.unet.down) for (auto& t : d.attn) forget(t);
+    forget(c.unet.mid_attn);
+    for (auto& d : c.unet.up) for (auto& t : d.attn) forget(t);
+    auto forget_sd = [](SDTransformer& t) { t.kv = nullptr; };
+    auto forget_trunk = [&](SDTrunk& tr) { for (auto& d : tr.down) for (auto& t : d.attn) forget_sd(t); forget_sd(tr.mid_attn); };
+    for (SDUNetM* u : {&c.sn.unet_y, &c.sn.unet_r}) { forget_trunk(u->tr); for (auto& d : u->up) for (auto& t : d.attn) forget_sd(t); u->ts.tproj = nullptr; u->ts.steps = 0; }
+    for (ControlNetM* m : {&c.sn.ctrl_y, &c.sn.ctrl_d}) { forget_trunk(m->tr); m->ts.tproj = nullptr; m->ts.steps = 0; }
+  }
+};
+
+// ------------------------------------------------------------------ lanes
+// Issue `ntask` mutually independent sub-graphs.  body(i) enqueues task i on c.stream with transient memory from c.ws and must write its
+// results into buffers the caller allocated beforehand.  `kind(i)` names the task's shape (e.g. "dec:8x384x512"): the first time a kind runs
+// it runs alone on the main stream and the arena bytes it needed are recorded; from then on tasks are spread over up to c.concurrency
+// lanes, each with a private arena slice of the recorded size, forked from / joined to the main stream with events.  The kernels and
+// their launch parameters are the same either way, so outputs are bit-identical (tests/test_pipeline_gpu.py).  Event-bracketed
+// profiling passes (c.prof_on) stay serial so that every kernel is timed alone.
+template <class Kind, class Body>
+static void run_lanes(Ctx& c, int ntask, Kind kind, Body body) {
+  std::vector<size_t> need(ntask, 0);
+  bool known = true;
+  for (int i = 0; i < ntask; ++i) {
+    auto it = c.lane_need.find(kind(i));
+    if (it == c.lane_need.end()) known = false; else need[i] = it->second;
+  }
+  int nl = std::min(c.concurrency, ntask);
+  size_t slice = 0;
+  for (size_t n : need) slice = std::max(slice, n);
+  slice = (slice + (1 << 20)) & ~(size_t)255;
+  if (known) while (nl > 1 && c.ws.mark() + (size_t)nl * slice > c.ws.capacity()) --nl;    // not enough arena for nl slices: fewer lanes
+  if (!known || nl <= 1 || c.prof_on) {
+    for (int i = 0; i < ntask; ++i) {
+      const size_t m0 = c.ws.mark();
+      c.ws.reset_high();
+      body(i);
+      c.lane_need[kind(i)] = c.ws.high() - m0;
+      UG_REQUIRE(c.ws.mark() == m0, "lane task must release its transient memory");
+    }
+    return;
+  }
+  while ((int)c.lanes.size() < nl) {
+    Lane l;
+    UG_CHECK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+    UG_CHECK(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
+    c.lanes.push_back(l);
+  }
+  if (!c.fork_ev) UG_CHECK(hipEventCreateWithFlags(&c.fork_ev, hipEventDisableTiming));
+  const size_t mk = c.ws.mark();
+  char* base = (char*)c.ws.alloc((size_t)nl * slice);
+  hipStream_t main_stream = c.stream;
+  Arena main_ws = c.ws;
+  UG_CHECK(hipEventRecord(c.fork_ev, main_stream));
+  for (int l = 0; l < nl; ++l) UG_CHECK(hipStreamWaitEvent(c.lanes[l].stream, c.fork_ev, 0));
+  // longest task first, each to the lane with the least work so far (need is a fair proxy for a chunk's cost)
+  std::vector<int> order(ntask); for (int i = 0; i < ntask; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return need[a] > need[b]; });
+  std::vector<size_t> load(nl, 0);
+  std::vector<std::vector<int>> plan(nl);
+  for (int i : order) { const int l = (int)(std::min_element(load.begin(), load.end()) - load.begin()); plan[l].push_back(i); load[l] += need[i] + 1; }
+  try {
+    // round-robin over the lanes' queues so that the host feeds all streams evenly
+    for (size_t k = 0;; ++k) {
+      bool any = false;
+      for (int l = 0; l < nl; ++l) {
+        if (k >= plan[l].size()) continue;
+        any = true;
+        c.stream = c.lanes[l].stream;
+        c.ws.view(base + (size_t)l * slice, slice);
+        body(plan[l][k]);
+      }
+      if (!any) break;
+    }
+  } catch (...) {
+    c.stream = main_stream; c.ws = main_ws;
+    for (int l = 0; l < nl; ++l) (void)hipStreamSynchronize(c.lanes[l].stream);
+    c.ws.release(mk);
+    throw;
+  }
+  c.stream = main_stream; c.ws = main_ws;
+  for (int l = 0; l < nl; ++l) {
+    UG_CHECK(hipEventRecord(c.lanes[l].done, c.lanes[l].stream));
+    UG_CHECK(hipStreamWaitEvent(main_stream, c.lanes[l].done, 0));
+  }
+  c.ws.release(mk);    // stream-ordered: whatever reuses these bytes is enqueued behind the joins
 }
 
 // ------------------------------------------------------------------ profiling
@@ -817,7 +916,9 @@ static void ff_pair(Ctx& c, const f16* a, long M, const Lin& f1, const Lin& f2, 
   }
   const long bytes = M * C4 * 2;
   int nchunk = 1;
-  if (bytes > (96L << 20) && getenv("UG_FF_CHUNK")) nchunk = (int)((bytes + (48L << 20) - 1) / (48L << 20));
+  // row chunking is an opt-in experiment; never together with a pre-quantised MX-fp8 input (q: the LayerNorm then wrote ONLY the fp8 image of
+  // `a`, whole rows x all K steps - a chunk would need offsets into it, and the fp16 `a` the chunks read was never written)
+  if (bytes > (96L << 20) && getenv("UG_FF_CHUNK") && !q) nchunk = (int)((bytes + (48L << 20) - 1) / (48L << 20));
   const long rows = ((M + nchunk - 1) / nchunk + 255) / 256 * 256;
   for (long r0 = 0; r0 < M; r0 += rows) {
     const long m = std::min(rows, M - r0);
@@ -1364,21 +1465,35 @@ void dc_run(Ctx& c, int steps, int chunk, int with_normals, int window, int over
   if (windows) UG_REQUIRE(window <= 128 && overlap >= 0 && overlap < window, "window must be <= 128 frames and overlap < window");
   else UG_REQUIRE(T <= 128, "more than 128 frames need latent sliding windows (window <= 128)");
   const long px = (long)T * H * W, lp = (long)T * h * w;
-  const size_t mk = c.ws.mark();
+  RunGuard guard(c);
   // 1. inputs -> fp16, [-1,1], noise augmentation
   f16* clip_src = c.ws.get<f16>(px * 3);
   f16* vae_in = c.ws.get<f16>(px * 8);
   launch_prep_video(c.d_frames, c.d_noise_aug, clip_src, vae_in, T, H, W, 0.02f, c.stream);
-  // 2. CLIP image embeddings (per frame)
-  f16* emb = clip_embed(c, clip_src, T, H, W);
-  // 3. VAE encode -> conditioning latents (mode of the posterior, unscaled)
+  // 2. CLIP image embeddings (per frame) and 3. VAE encode -> conditioning latents (mode of the posterior, unscaled), `chunk` frames at a
+  // time as the reference does.  The CLIP tower and the encoder chunks are independent of each other: run_lanes spreads them over streams.
+  f16* emb = c.ws.get<f16>((long)T * c.clip.cfg.proj);
   f16* cond = c.ws.get<f16>(lp * 4);
-  for (int t0 = 0; t0 < T; t0 += chunk) {
-    const int tc = std::min(chunk, T - t0);
-    const size_t m2 = c.ws.mark();
-    f16* l = vae_encode(c, vae_in + (long)t0 * H * W * 8, tc, H, W);
-    UG_CHECK(hipMemcpyAsync(cond + (long)t0 * h * w * 4, l, (size_t)tc * h * w * 4 * 2, hipMemcpyDeviceToDevice, c.stream));
-    c.ws.release(m2);
+  {
+    const int nchunks = (T + chunk - 1) / chunk;
+    auto kind = [&](int i) {
+      char b[96];
+      if (i == nchunks) snprintf(b, sizeof(b), "clip:%dx%dx%d", T, H, W);
+      else snprintf(b, sizeof(b), "enc%d:%dx%dx%d", c.vae_encode_fp32, std::min(chunk, T - i * chunk), H, W);
+      return std::string(b);
+    };
+    run_lanes(c, nchunks + 1, kind, [&](int i) {
+      const size_t m2 = c.ws.mark();
+      if (i == nchunks) {
+        f16* e = clip_embed(c, clip_src, T, H, W);
+        UG_CHECK(hipMemcpyAsync(emb, e, (size_t)T * c.clip.cfg.proj * 2, hipMemcpyDeviceToDevice, c.stream));
+      } else {
+        const int t0 = i * chunk, tc = std::min(chunk, T - t0);
+        f16* l = vae_encode(c, vae_in + (long)t0 * H * W * 8, tc, H, W);
+        UG_CHECK(hipMemcpyAsync(cond + (long)t0 * h * w * 4, l, (size_t)tc * h * w * 4 * 2, hipMemcpyDeviceToDevice, c.stream));
+      }
+      c.ws.release(m2);
+    });
   }
   // 4. scheduler tables + latents
   std::vector<float> sig, ts;
@@ -1456,9 +1571,13 @@ void dc_run(Ctx& c, int steps, int chunk, int with_normals, int window, int over
   // 6. decode in chunks of `chunk` frames (temporal layers only see the chunk, as in the reference)
   f16* z = c.ws.get<f16>(lp * 4);
   launch_scale_f16(lat, z, 1.0f / c.vae.cfg.scaling, lp * 4, c.stream);
-  for (int t0 = 0; t0 < T; t0 += chunk) {
-    const int tc = std::min(chunk, T - t0);
-    vae_decode(c, z + (long)t0 * h * w * 4, tc, h, w, c.d_out_frames + (long)t0 * H * W * 3);
+  {
+    const int nchunks = (T + chunk - 1) / chunk;
+    auto kind = [&](int i) { char b[96]; snprintf(b, sizeof(b), "dec:%dx%dx%d", std::min(chunk, T - i * chunk), h, w); return std::string(b); };
+    run_lanes(c, nchunks, kind, [&](int i) {
+      const int t0 = i * chunk, tc = std::min(chunk, T - t0);
+      vae_decode(c, z + (long)t0 * h * w * 4, tc, h, w, c.d_out_frames + (long)t0 * H * W * 3);
+    });
   }
   // 7. wrapper post-processing on device
   launch_depth_post(c.d_out_frames, c.d_depth, c.d_mm, px, c.stream);
@@ -1467,7 +1586,6 @@ void dc_run(Ctx& c, int steps, int chunk, int with_normals, int window, int over
     launch_normals(c.d_depth, c.d_K, c.d_normals, T, H, W, c.stream);
   }
   UG_CHECK(hipStreamSynchronize(c.stream));
-  c.ws.release(mk);
 }
 
 void dc_get_outputs(Ctx& c, float* frames, float* depth, float* normals) {

@@ -216,8 +216,8 @@ __device__ __forceinline__ void fa_tile_wide(const f16* kt, const f16* vt, const
       }
 }
 
-static int g_fa_wide = 7;   // A/B knob (ug_tune_flash): bit 0 = fa_tile_wide, bit 1 = XCD-grouped workgroup order, bit 2 = 2-slot ring + 4 workgroups per CU
-void flash_set_variant(int v) { g_fa_wide = v; }
+static int g_fa_default = 7;   // process default of FlashP::variant (ug_tune_flash, a test aid): bit 0 = fa_tile_wide, bit 1 = XCD-grouped workgroup order, bit 2 = 2-slot ring + 4 workgroups per CU
+void flash_set_variant(int v) { g_fa_default = v; }
 
 // The grid is 1-D: workgroup L runs on XCD L % 8, and each XCD has its own L2.  With the natural order the query blocks of one
 // (frame, head) are dealt round-robin to all 8 XCDs, so every L2 fetches that head's K / V for itself; the permutation below hands each
@@ -344,6 +344,7 @@ void launch_flash_attn64(const FlashP& p, hipStream_t s) {
   const int nqb = cdiv(p.S, 128 * FA_QB);
   const long total = (long)nqb * p.H * p.B;
   UG_REQUIRE(total < (1L << 31), "flash attention grid");
+  const int g_fa_wide = p.variant >= 0 ? p.variant : g_fa_default;
   const int xcd_group = (total % 8 == 0 && (g_fa_wide & 2)) ? 1 : 0;
   if (g_fa_wide & 4) {   // A/B: 2-slot ring (32 KiB) and 4 workgroups per CU
     if (g_fa_wide & 1) hipLaunchKernelGGL((flash_attn64_kernel<true, 2, 4>), dim3((unsigned)total), dim3(256), 0, s, p, nqb, xcd_group);

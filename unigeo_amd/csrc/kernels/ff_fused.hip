@@ -328,8 +328,9 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
 template <int KT>
 static void launch_ff_t(const FFusedP& p, hipStream_t s) {
   const size_t lds = (size_t)(KT + 3 + 1) * 128 * 64 * sizeof(f16);
-  static bool attr = false;
-  if (!attr) { UG_CHECK(hipFuncSetAttribute((const void*)ff_fused_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  static bool attr[32] = {};
+  bool& at = attr[ug_dev_slot()];
+  if (!at) { UG_CHECK(hipFuncSetAttribute((const void*)ff_fused_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); at = true; }
   const int ntiles = (p.M + 127) / 128;
   const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / lds)));
   const int grid = std::min(ntiles, per_cu * 256);

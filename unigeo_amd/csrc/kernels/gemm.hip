@@ -1115,11 +1115,12 @@ static void launch_ws(const GemmP& p, int batch, hipStream_t s) {
 #else
   const size_t lds = 3 * (BM + BN) * 64 * sizeof(f16);
 #endif
-  static bool attr = false;
-  if (!attr) {
+  static bool attr[32] = {};
+  bool& at = attr[ug_dev_slot()];
+  if (!at) {
     UG_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<BM, BN, WMW, WNW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     UG_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<BM, BN, WMW, WNW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = true;
+    at = true;
   }
   const int split = p.splitk > 1 ? p.splitk : 1;
   int gx = std::max(8, 256 / (split * batch));
@@ -1139,11 +1140,12 @@ static void launch_ldr(const GemmP& p, int batch, hipStream_t s) {
 #else
   const size_t lds = (size_t)NST * (BM + BN) * 64 * sizeof(f16);
 #endif
-  static bool attr = false;
-  if (!attr) {
+  static bool attr[32] = {};
+  bool& at = attr[ug_dev_slot()];
+  if (!at) {
     UG_CHECK(hipFuncSetAttribute((const void*)gemm_ldr_kernel<BM, BN, NST, WMW, WNW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     UG_CHECK(hipFuncSetAttribute((const void*)gemm_ldr_kernel<BM, BN, NST, WMW, WNW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = true;
+    at = true;
   }
   const int per_cu = (160 * 1024) / (int)lds < 1 ? 1 : std::min(2, (160 * 1024) / (int)lds);
   const int split = p.splitk > 1 ? p.splitk : 1;
@@ -1205,11 +1207,13 @@ static void launch_t(const GemmP& p, int batch, hipStream_t s) {
   const size_t lds = (size_t)NST * (BM + BN) * BK * sizeof(f16);
 #endif
   auto kern = gemm_kernel<BM, BN, BK, NST, WMW, WNW, CONV, UNI, BUFA>;
-  static int per_cu = 0;
-  if (!per_cu) {
+  static bool attr[32] = {};
+  bool& at = attr[ug_dev_slot()];
+  if (!at) {
     if (lds > 64 * 1024) UG_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    per_cu = GemmOcc<BM, BN, BK, NST, WMW, WNW>::wg;
+    at = true;
   }
+  const int per_cu = GemmOcc<BM, BN, BK, NST, WMW, WNW>::wg;
   const int split = p.splitk > 1 ? p.splitk : 1;
   // persistent grid: at most (co-resident workgroups per CU) x 256 CUs, shared with the other grid dimensions
   const int cap = std::max(8, (per_cu * 256) / (split * batch));
@@ -1282,8 +1286,9 @@ static void launch_mx_t(const GemmP& p, hipStream_t s) {
   const int ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
   const size_t lds = (size_t)NST * (BM + BN) * 64 * sizeof(f16) + (size_t)NST * (BM + BN) * 4;
   auto kern = gemm_kernel<BM, BN, 64, NST, WMW, WNW, false, false, BUFA, true>;
-  static bool attr = false;
-  if (!attr) { UG_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  static bool attr[32] = {};
+  bool& at = attr[ug_dev_slot()];
+  if (!at) { UG_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); at = true; }
   const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / lds)));
   int gx = (per_cu * 256 / 8) * 8;
   gx = std::min(gx, ntiles);

@@ -30,7 +30,8 @@ class DepthCrafter:
         print(f"Using device: {self.device}")
         have = bool(unet_path) and bool(pre_train_path) and os.path.isdir(unet_path) and os.path.isdir(pre_train_path)
         if have:
-            self.pipeline = DepthCrafterPipelineHIP.from_pretrained(pre_train_path, unet_path, device_id=device_id)
+            kw = {"workspace_bytes": kwargs["workspace_bytes"]} if kwargs.get("workspace_bytes") else {}
+            self.pipeline = DepthCrafterPipelineHIP.from_pretrained(pre_train_path, unet_path, device_id=device_id, **kw)
         elif kwargs.get("synthetic_weights", False):
             cfgs = kwargs.get("cfgs")
             if cfgs is None and kwargs.get("tiny", False):      # YAML-selectable tiny full-topology configuration (plumbing checks)

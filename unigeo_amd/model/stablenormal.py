@@ -14,17 +14,25 @@ Here ``self.predictor`` is ``StableNormalPredictorHIP`` (unigeo_amd/stablenormal
   * a caller-supplied ``predictor=`` (any callable image -> uint8 normal image) is still honoured.
 """
 import os
+import warnings
 
 import numpy as np
 
+PARITY_NOTE = ("StableNormal on the MI355X engine is a RESTATEMENT of the published design (DESIGN.md section 9): it has never been run next to the "
+               "torch.hub predictor the reference loads (model/stablenormal.py:16), so its normals are NOT known to be comparable with the "
+               "reference's - parity unpinned.  Pass predictor=<callable> to drive the plugin with the hub predictor itself.")
+
 
 class StableNormal:
+    parity = "unpinned"
+
     def __init__(self, **kwargs):
         device_id = int(kwargs.get("device_id", 0))
         self.device = f"hip:{device_id}"
         print(f"Using device: {self.device}")
         self.predictor = kwargs.get("predictor")
         if self.predictor is None:
+            warnings.warn(PARITY_NOTE, stacklevel=2)       # said at run time, not only in the docs (ADVICE r2)
             from ..stablenormal import StableNormalPredictorHIP
             from .. import weights as W
             opts = {k: kwargs[k] for k in ("yoso_timestep", "refine_start", "refine_steps", "prediction_type", "workspace_bytes") if k in kwargs}
@@ -38,6 +46,7 @@ class StableNormal:
             else:
                 raise FileNotFoundError(f"StableNormal checkpoints not found under model_dir={model_dir!r}; pass synthetic_weights=True "
                                         "for seeded random weights of the same architecture, or predictor=<callable>")
+        self.parity = getattr(self.predictor, "parity", "caller-supplied predictor")
         print("Model loaded")
 
     def prepare_input(self, data):
@@ -58,7 +67,9 @@ class StableNormal:
         if hasattr(self.predictor, "predict_batch"):
             from ..stablenormal import normals_to_uint8
             n = self.predictor.predict_batch(self.prepare_input(data))       # uint8-truncated frames, one batch
-            return self.postprocess(list(normals_to_uint8(n)))
+            out = self.postprocess(list(normals_to_uint8(n)))
+            out["parity"] = self.parity                                      # extra key (the harness reads pred_normals / pred_depths only)
+            return out
         from PIL import Image
         images = [Image.fromarray(np.asarray(x).transpose(1, 2, 0).astype(np.uint8)) for x in data["images"]]
         return self.postprocess([self.predictor(im) for im in images])

@@ -56,8 +56,8 @@ class DepthCrafterPipelineHIP:
     def from_pretrained(cls, pre_train_path, unet_path, device_id=0, **kw):
         """diffusers directory layout (SVD-XT dir + DepthCrafter UNet dir); hard-fails on any tensor
         name/shape that disagrees with the architecture restated by this build."""
-        u, v, c = W.load_pretrained(unet_path, pre_train_path)
-        return cls.from_state(u, v, c, device_id=device_id, **kw)
+        u, v, c, cfgs = W.load_pretrained(unet_path, pre_train_path, with_cfgs=True)    # architecture from the three config.json files
+        return cls.from_state(u, v, c, cfgs=cfgs, device_id=device_id, **kw)
 
     @classmethod
     def from_random(cls, seed=42, cfgs=None, device_id=0, **kw):

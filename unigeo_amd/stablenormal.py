@@ -64,6 +64,8 @@ def manifests(cfgs):
 class StableNormalPredictorHIP:
     """Drop-in for the hub ``Predictor``: ``predictor(pil_image) -> pil_normal_image``; ``predict_batch`` takes a whole clip."""
 
+    parity = "unpinned"      # restated from the published design, never run next to the hub predictor (DESIGN.md section 9)
+
     def __init__(self, engine, cfgs, prompt_embeds, yoso_timestep=999, refine_start=401, refine_steps=10, prediction_type="v_prediction"):
         self.engine, self.cfgs = engine, cfgs
         self.prompt_embeds = np.ascontiguousarray(prompt_embeds, dtype=np.float32)

@@ -297,19 +297,151 @@ def _first_existing(d, names):
     raise FileNotFoundError(f"none of {names} under {d}")
 
 
-def load_pretrained(unet_path: str, pre_train_path: str):
-    """diffusers directory layout -> (unet_state, vae_state, clip_state), checked against the
-    manifests.  Raises with a precise diff if the files disagree with the restated architecture."""
+# Scheduler constants the engine's Karras / Euler tables are built from (csrc/engine.hip: karras_sigmas, k_euler_step; oracle/scheduler.py)
+# = scheduler/scheduler_config.json of stable-video-diffusion-img2vid-xt.  A checkpoint whose file says otherwise must not load silently.
+SCHEDULER_EXPECTED = {"_class_name": "EulerDiscreteScheduler", "sigma_min": 0.002, "sigma_max": 700.0, "prediction_type": "v_prediction",
+                      "timestep_spacing": "leading", "timestep_type": "continuous", "use_karras_sigmas": True, "num_train_timesteps": 1000,
+                      "steps_offset": 1, "interpolation_type": "linear"}
+KARRAS_RHO = 7.0          # diffusers hard-codes rho = 7 in EulerDiscreteScheduler._convert_to_karras (not a config key)
+
+
+def _read_json(path, what):
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{what}: {path} is missing (the reference's from_pretrained reads it, model/depthcrafter.py:18-29)")
+    with open(path) as f:
+        return json.load(f)
+
+
+def _require(cfg, key, want, what):
+    if key not in cfg:
+        return                      # older config files omit keys whose default is the restated value
+    got = cfg[key]
+    same = (abs(float(got) - float(want)) <= 1e-9 * max(1.0, abs(float(want)))) if isinstance(want, float) else (got == want)
+    if not same:
+        raise ValueError(f"{what}: {key} = {got!r} but this build restates {want!r}; refusing to load a checkpoint the kernels were not written for")
+
+
+def check_scheduler_config(cfg: dict, what="scheduler/scheduler_config.json"):
+    for k, v in SCHEDULER_EXPECTED.items():
+        _require(cfg, k, v, what)
+
+
+def unet_cfg_from_config(cfg: dict) -> UNetCfg:
+    """diffusers ``UNetSpatioTemporalConditionModel`` config.json -> UNetCfg.  Keys that select code this build does not have fail."""
+    what = "UNet config.json"
+    down = list(cfg.get("down_block_types", ["CrossAttnDownBlockSpatioTemporal"] * 3 + ["DownBlockSpatioTemporal"]))
+    up = list(cfg.get("up_block_types", ["UpBlockSpatioTemporal"] + ["CrossAttnUpBlockSpatioTemporal"] * 3))
+    ok_d = {"CrossAttnDownBlockSpatioTemporal": True, "DownBlockSpatioTemporal": False}
+    ok_u = {"CrossAttnUpBlockSpatioTemporal": True, "UpBlockSpatioTemporal": False}
+    if any(d not in ok_d for d in down) or any(u not in ok_u for u in up):
+        raise ValueError(f"{what}: unsupported block types {down} / {up}")
+    has = tuple(ok_d[d] for d in down)
+    if tuple(ok_u[u] for u in up) != tuple(reversed(has)):
+        raise ValueError(f"{what}: up_block_types {up} are not the mirror of down_block_types {down}")
+    if has[-1] or not all(has[:-1]):
+        raise ValueError(f"{what}: this build has attention on every level but the last ({down})")
+    tl = cfg.get("transformer_layers_per_block", 1)
+    if (tl if isinstance(tl, int) else max(tl)) != 1:
+        raise ValueError(f"{what}: transformer_layers_per_block = {tl} (this build: 1)")
+    heads = cfg.get("num_attention_heads", (5, 10, 20, 20))
+    boc = tuple(cfg["block_out_channels"])
+    heads = tuple(heads) if not isinstance(heads, int) else (heads,) * len(boc)
+    lpb = cfg.get("layers_per_block", 2)
+    if not isinstance(lpb, int):
+        if len(set(lpb)) != 1:
+            raise ValueError(f"{what}: per-level layers_per_block {lpb} not supported")
+        lpb = lpb[0]
+    if any(c % h or c // h != 64 for c, h in zip(boc, heads)):
+        raise ValueError(f"{what}: attention head dim must be 64 (block_out_channels {boc}, num_attention_heads {heads})")
+    d = UNetCfg()
+    return UNetCfg(in_channels=cfg.get("in_channels", 8), out_channels=cfg.get("out_channels", 4), block_out_channels=boc, layers_per_block=lpb,
+                   num_attention_heads=heads, cross_attention_dim=cfg.get("cross_attention_dim", 1024),
+                   addition_time_embed_dim=cfg.get("addition_time_embed_dim", 256),
+                   projection_class_embeddings_input_dim=cfg.get("projection_class_embeddings_input_dim", 768),
+                   norm_groups=cfg.get("norm_num_groups", d.norm_groups),     # not a diffusers key (hard-coded 32 there); written by save_pretrained_layout for reduced configurations
+                   down_has_attn=has)
+
+
+def vae_cfg_from_config(cfg: dict) -> VAECfg:
+    what = "VAE config.json"
+    _require(cfg, "_class_name", "AutoencoderKLTemporalDecoder", what)
+    if not cfg.get("force_upcast", True):
+        raise ValueError(f"{what}: force_upcast = false - the engine runs the reference's float32 encoder; call ug_set_vae_encode_fp32(0) explicitly instead")
+    return VAECfg(in_channels=cfg.get("in_channels", 3), out_channels=cfg.get("out_channels", 3), latent_channels=cfg.get("latent_channels", 4),
+                  block_out_channels=tuple(cfg["block_out_channels"]), layers_per_block=cfg.get("layers_per_block", 2),
+                  norm_groups=cfg.get("norm_num_groups", VAECfg().norm_groups), scaling_factor=float(cfg.get("scaling_factor", 0.18215)))
+
+
+def clip_cfg_from_config(cfg: dict) -> CLIPCfg:
+    what = "image_encoder config.json"
+    _require(cfg, "hidden_act", "gelu", what)      # erf GELU (the engine's epilogue); "quick_gelu" towers would need another one
+    return CLIPCfg(hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"], num_hidden_layers=cfg["num_hidden_layers"],
+                   num_attention_heads=cfg["num_attention_heads"], image_size=cfg.get("image_size", 224), patch_size=cfg.get("patch_size", 14),
+                   projection_dim=cfg.get("projection_dim", 1024), layer_norm_eps=float(cfg.get("layer_norm_eps", 1e-5)))
+
+
+def load_pretrained(unet_path: str, pre_train_path: str, with_cfgs: bool = False):
+    """What the reference's two ``from_pretrained`` calls read (model/depthcrafter.py:18-29), in the diffusers directory layout:
+
+        unet_path/config.json, unet_path/diffusion_pytorch_model.safetensors                  (DepthCrafter UNet; fp32 file, cast to fp16)
+        pre_train_path/vae/config.json, vae/diffusion_pytorch_model.fp16.safetensors           (variant="fp16")
+        pre_train_path/image_encoder/config.json, image_encoder/model.fp16.safetensors
+        pre_train_path/scheduler/scheduler_config.json
+
+    -> (unet_state, vae_state, clip_state[, (UNetCfg, VAECfg, CLIPCfg)]).  The three config.json files give the architecture (so a reduced
+    configuration loads too); every tensor is checked against the manifest of that architecture, and the scheduler file against the constants
+    the engine's sigma tables are built from.  Any disagreement raises with a precise diff - nothing loads on a best-effort basis."""
+    ucfg = unet_cfg_from_config(_read_json(os.path.join(unet_path, "config.json"), "UNet"))
+    vcfg = vae_cfg_from_config(_read_json(os.path.join(pre_train_path, "vae", "config.json"), "VAE"))
+    ccfg = clip_cfg_from_config(_read_json(os.path.join(pre_train_path, "image_encoder", "config.json"), "CLIP image encoder"))
+    check_scheduler_config(_read_json(os.path.join(pre_train_path, "scheduler", "scheduler_config.json"), "scheduler"))
+    if ucfg.cross_attention_dim != ccfg.projection_dim:
+        raise ValueError(f"UNet cross_attention_dim {ucfg.cross_attention_dim} != image encoder projection_dim {ccfg.projection_dim}")
     u = load_safetensors(_first_existing(unet_path, [
         "diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.fp16.safetensors"]))
     v = load_safetensors(_first_existing(os.path.join(pre_train_path, "vae"), [
         "diffusion_pytorch_model.fp16.safetensors", "diffusion_pytorch_model.safetensors"]))
     c = load_safetensors(_first_existing(os.path.join(pre_train_path, "image_encoder"), [
         "model.fp16.safetensors", "model.safetensors"]))
-    check_against_manifest(u, unet_manifest(), "UNet")
-    check_against_manifest(v, vae_manifest(), "VAE")
-    check_against_manifest(c, clip_manifest(), "CLIP image encoder")
-    return u, v, c
+    check_against_manifest(u, unet_manifest(ucfg), "UNet")
+    check_against_manifest(v, vae_manifest(vcfg), "VAE")
+    check_against_manifest(c, clip_manifest(ccfg), "CLIP image encoder")
+    return (u, v, c, (ucfg, vcfg, ccfg)) if with_cfgs else (u, v, c)
+
+
+def save_pretrained_layout(unet_path: str, pre_train_path: str, unet_state, vae_state, clip_state, cfgs=None, unet_dtype=np.float32):
+    """Write states in the directory layout ``load_pretrained`` reads - the inverse, used by the tests (tiny configurations) and by
+    tools that stage seeded weights as a checkpoint.  The UNet file is fp32 like the DepthCrafter release; VAE / image encoder are the
+    ``variant="fp16"`` files.  config.json / scheduler_config.json carry exactly the keys the loader checks."""
+    from safetensors.numpy import save_file
+    u, v, c = cfgs or (UNetCfg(), VAECfg(), CLIPCfg())
+    for d in (unet_path, os.path.join(pre_train_path, "vae"), os.path.join(pre_train_path, "image_encoder"), os.path.join(pre_train_path, "scheduler")):
+        os.makedirs(d, exist_ok=True)
+    save_file({k: np.ascontiguousarray(a.astype(unet_dtype)) for k, a in unet_state.items()}, os.path.join(unet_path, "diffusion_pytorch_model.safetensors"))
+    save_file({k: np.ascontiguousarray(a.astype(np.float16)) for k, a in vae_state.items()},
+              os.path.join(pre_train_path, "vae", "diffusion_pytorch_model.fp16.safetensors"))
+    save_file({k: np.ascontiguousarray(a.astype(np.float16)) for k, a in clip_state.items()},
+              os.path.join(pre_train_path, "image_encoder", "model.fp16.safetensors"))
+    n = len(u.block_out_channels)
+    down = ["CrossAttnDownBlockSpatioTemporal" if a else "DownBlockSpatioTemporal" for a in u.down_has_attn[:n]]
+    up = ["CrossAttnUpBlockSpatioTemporal" if a else "UpBlockSpatioTemporal" for a in reversed(u.down_has_attn[:n])]
+    with open(os.path.join(unet_path, "config.json"), "w") as f:
+        json.dump({"_class_name": "UNetSpatioTemporalConditionModel", "in_channels": u.in_channels, "out_channels": u.out_channels,
+                   "down_block_types": down, "up_block_types": up, "block_out_channels": list(u.block_out_channels),
+                   "layers_per_block": u.layers_per_block, "num_attention_heads": list(u.num_attention_heads),
+                   "cross_attention_dim": u.cross_attention_dim, "addition_time_embed_dim": u.addition_time_embed_dim,
+                   "projection_class_embeddings_input_dim": u.projection_class_embeddings_input_dim, "transformer_layers_per_block": 1,
+                   "norm_num_groups": u.norm_groups, "num_frames": 25, "sample_size": 96}, f, indent=1)
+    with open(os.path.join(pre_train_path, "vae", "config.json"), "w") as f:
+        json.dump({"_class_name": "AutoencoderKLTemporalDecoder", "in_channels": v.in_channels, "out_channels": v.out_channels,
+                   "latent_channels": v.latent_channels, "block_out_channels": list(v.block_out_channels), "layers_per_block": v.layers_per_block,
+                   "norm_num_groups": v.norm_groups, "scaling_factor": v.scaling_factor, "force_upcast": True, "sample_size": 768}, f, indent=1)
+    with open(os.path.join(pre_train_path, "image_encoder", "config.json"), "w") as f:
+        json.dump({"architectures": ["CLIPVisionModelWithProjection"], "hidden_act": "gelu", "hidden_size": c.hidden_size,
+                   "intermediate_size": c.intermediate_size, "num_hidden_layers": c.num_hidden_layers, "num_attention_heads": c.num_attention_heads,
+                   "image_size": c.image_size, "patch_size": c.patch_size, "projection_dim": c.projection_dim, "layer_norm_eps": c.layer_norm_eps}, f, indent=1)
+    with open(os.path.join(pre_train_path, "scheduler", "scheduler_config.json"), "w") as f:
+        json.dump({**SCHEDULER_EXPECTED, "beta_start": 0.00085, "beta_end": 0.012, "beta_schedule": "scaled_linear"}, f, indent=1)
 
 
 # ------------------------------------------------------------------------------------------------------------------
