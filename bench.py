@@ -103,9 +103,9 @@ def calibration_probe(eng):
     try:
         eng.bench_gemm(8192, 8192, 8192, iters=3)
         ms, tf, cfg, _ = eng.bench_gemm(8192, 8192, 8192, iters=10)
-        out["gemm_8192_tflops"] = round(tf, 1)
+        out["gemm_8192_tflops"] = round(float(tf), 1)
         us = eng.bench_groupnorm(128, 0, 16, 196608, 0, 1, iters=10)
-        out["groupnorm_stream_gbps"] = round(16 * 196608 * 128 * 2 * 3 / (us * 1e-6) / 1e9, 1)
+        out["groupnorm_stream_gbps"] = round(float(16 * 196608 * 128 * 2 * 3 / (us * 1e-6) / 1e9), 1)
     except Exception as e:   # a probe must never cost the headline
         out["error"] = repr(e)
     return out
@@ -242,7 +242,7 @@ def main():
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "config0", "sample"],
                     help="config0 = BASELINE configs[0] as stated (25 frames 384x512, 2 Euler steps on the host cores: ~3-4 min on 32 threads); "
                          "sample = a 3-frame 192x256 clip (~10 s) extrapolated by algorithmic work; auto = config0 with >= 16 host cores")
-    ap.add_argument("--lanes", type=int, default=3, help="independent chunks (VAE encode / decode chunks, CLIP) in flight on separate HIP streams; 1 = serial")
+    ap.add_argument("--lanes", type=int, default=1, help="independent chunks (VAE encode / decode chunks, CLIP) in flight on separate HIP streams; 1 = serial")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the with-normals / N=5 / fp16-encoder / fp8 side rates (rocprofv3 runs)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path (RCCL process group, all_gather, barriers, "

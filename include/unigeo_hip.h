@@ -97,7 +97,7 @@ int ug_dc_get_outputs(ug_ctx* ctx, float* frames_out, float* depth_out, float* n
  * fp32 residual stream / GroupNorm / softmax, GEMMs on fp16 hi/lo activation pairs against the (fp16-valued) weights, which is
  * exact to fp32 rounding.  on = 0: fp16 storage with fp32 accumulation, like the decoder (faster, ~1e-3 off the fp32 result). */
 int ug_set_vae_encode_fp32(ug_ctx* ctx, int on);
-/* Independent sub-graphs of one pipeline call in flight at a time (default 3; 1 = strictly one kernel after another).  The reference's
+/* Independent sub-graphs of one pipeline call in flight at a time (default 1 = strictly one kernel after another; 2 measured -0.6 % on the headline clip).  The reference's
  * pipeline encodes / decodes the clip in chunks of `decode_chunk_size` frames one after the other and computes the CLIP embeddings before
  * them (the calls inside pipeline(...) at model/depthcrafter.py:80-90); those chunks do not depend on each other, so the engine issues them on
  * separate HIP streams - one chunk's HBM-bound passes overlap another's MFMA-bound ones.  Same kernels, same launch parameters:
@@ -148,6 +148,11 @@ int ug_sn_unet_forward(ug_ctx* ctx, int which, const float* sample_bchw, const f
                        float t_ctrl, const float* prompt_embeds, const float* dino_tokens, int use_ctrl, float* out_bchw);
 int ug_sn_dino(ug_ctx* ctx, const float* images_bhwc, int B, int H, int W, float* tokens_out /*[B, g*g, D]*/);
 int ug_sn_vae_decode(ug_ctx* ctx, const float* z_bchw, int B, int h, int w, float* out_bhwc /*[B,8h,8w,3] raw decoder output*/);
+/* Antialiased bilinear resize [B,Hi,Wi,C] -> [B,Ho,Wo,C] (float32, C <= 4) on the device = torch F.interpolate(mode="bilinear",
+ * align_corners=False, antialias=True); normalise = 1 re-normalises the channel vector of every output pixel (unit normals).  Used by the
+ * StableNormal predictor's optional processing resolution (the hub predictor behind model/stablenormal.py:16,39 resizes its input to a fixed
+ * processing resolution and the prediction back - DESIGN.md section 9, S1). */
+int ug_resize_bilinear(ug_ctx* ctx, const float* in_bhwc, int B, int Hi, int Wi, int C, int Ho, int Wo, int normalise, float* out_bhwc);
 int ug_sn_vae_encode(ug_ctx* ctx, const float* img_m11_bhwc, int B, int H, int W, float* lat_out /*[B,4,H/8,W/8] posterior mode, unscaled*/);
 
 /* Stage-level entry points (host in / host out) - what the parity tests drive.  Each replaces
@@ -197,7 +202,7 @@ int ug_op_euler_step(ug_ctx* ctx, const float* v, float* latents_inout, long n, 
 int ug_bench_groupnorm(ug_ctx* ctx, int C0, int C1, int T, int HW, int temporal, int mode, int iters, float* us_out);
 int ug_bench_gemm(ug_ctx* ctx, int M, int N, int K, int conv, int T, int Hi, int Wi, int C0, int C1, int kt, int k,
                   int stride, int ups, int cfg, int split, int iters, float* ms_out);
-int ug_tune_force(int cfg, int split);
+int ug_tune_force(ug_ctx* ctx, int cfg, int split);   /* test / A-B aid, per context: force a GEMM tile config (cfg >= 0) and split-K factor for this context's launches, (-1, -1) = planner; cfg = -100 - mask sets the knob mask (kernels/gemm.hip) */
 int ug_tune_flash(int variant);   /* test aid: process default of the flash-attention variant mask (bit 0: one softmax step per 64 keys, bit 1: XCD-grouped workgroup order, bit 2: 2-slot ring + 4 workgroups per CU; default 7).  ug_bench_flash passes its variant with the launch and leaves this alone. */
 
 /* HIP-event profiling of everything launched between begin and end; end returns a JSON

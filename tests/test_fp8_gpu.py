@@ -40,12 +40,12 @@ def test_mx8_tile_shapes_bitwise_identical(engine, pick):
     M, K, N = 2500, 640, 1280
     A, W, b = h16(rng.standard_normal((M, K))), h16(rng.standard_normal((N, K)) / np.sqrt(K)), h16(rng.standard_normal(N) * 0.1)
     try:
-        engine.lib.ug_tune_force(101, -1)
+        engine.tune_force(101, -1)
         ref = engine.op_linear_mx8(A, W, bias=b)
-        engine.lib.ug_tune_force(100 + pick, -1)
+        engine.tune_force(100 + pick, -1)
         got = engine.op_linear_mx8(A, W, bias=b)
     finally:
-        engine.lib.ug_tune_force(-1, -1)
+        engine.tune_force(-1, -1)
     assert np.array_equal(got, ref), f"MX tile pick {pick}: max diff {np.abs(got - ref).max()}"
 
 

@@ -39,7 +39,9 @@ def run():
         eng.set_inputs(frames, nl, na, K)
         tr = eng.run_traced(steps, 8, with_normals=True)                      # [steps,T,4,h,w] latents after every Euler step
         fr, depth, normals = eng.get_outputs(frames=True, depth=True, normals=True)
-        eng.run(steps, 8, with_normals=True)                                   # again, untraced, chunks on concurrent lanes: must not change a bit
+        eng.set_concurrency(3)
+        eng.run(steps, 8, with_normals=True)                                   # again, untraced, VAE chunks / CLIP on three concurrent lanes: must not change a bit
+        eng.set_concurrency(1)
         fr2, depth2, _ = eng.get_outputs(frames=True, depth=True, normals=False)
         cond = eng.vae_encode((frames[:2] * 2 - 1 + 0.02 * na[:2].transpose(0, 2, 3, 1)).astype(np.float16).astype(np.float32))
         emb = eng.clip_embed(frames[:4])

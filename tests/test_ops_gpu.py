@@ -326,7 +326,7 @@ def test_flash_attention_full_size_properties(engine):
 # (ring slot reuse, counted vmcnt, the asymmetric-loader kernels = configs 34 / 35 / 39, the producer / consumer kernels = 54 / 59 / 60) shows up as a difference.
 # ---------------------------------------------------------------------------------------------------
 def _force(engine, cfg):
-    engine.lib.ug_tune_force(cfg, 1 if cfg >= 0 else -1)
+    engine.tune_force(cfg, 1 if cfg >= 0 else -1)
 
 
 @pytest.mark.parametrize("cfg", [0, 1, 3, 4, 8, 12, 14, 19, 34, 35, 39, 54, 59, 60, 61, 62, 63, 64])
@@ -456,10 +456,10 @@ def test_conv_row_split_bitwise_full_size(engine, C1):
     b = rnd(rng, O)
     try:
         got = engine.op_conv(x, w, b, x1=x1)
-        engine.lib.ug_tune_force(-100 - 1024, 0)
+        engine.tune_force(-100 - 1024, 0)
         one = engine.op_conv(x, w, b, x1=x1)
     finally:
-        engine.lib.ug_tune_force(-100, 0)
+        engine.tune_force(-100, 0)
     assert np.array_equal(got, one), f"row split changes the result: max diff {np.abs(got - one).max()}"
     xin = x if x1 is None else np.concatenate([x, x1], -1)
     for t_ in (0, 21, 24):        # frame 21 straddles the split row (65536 = 21 frames + 1024 rows)

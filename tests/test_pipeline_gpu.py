@@ -144,6 +144,13 @@ def test_full_size_invariants():
         assert d1.min() >= 1 / 1.1 - 1e-5 and d1.max() <= 10 + 1e-4
         r2 = pipe(frames, num_inference_steps=1, window_size=T, noise_latents=nl, noise_aug=na)
         assert np.array_equal(r2.frames[0], f1) and np.array_equal(r2.depth, d1)
+        # the VAE encode / decode chunks and the CLIP tower on 2 / 3 concurrent HIP streams (ug_set_concurrency): same kernels, same launch
+        # parameters, disjoint outputs - not a bit may change
+        for lanes in (2, 3):
+            pipe.engine.set_concurrency(lanes)
+            r3 = pipe(frames, num_inference_steps=1, window_size=T, noise_latents=nl, noise_aug=na)
+            assert np.array_equal(r3.frames[0], f1) and np.array_equal(r3.depth, d1), f"{lanes} lanes changed the result"
+        pipe.engine.set_concurrency(1)
         eng = pipe.engine
         v = (frames[:9] * 2 - 1).astype(np.float32)
         a = eng.vae_encode(v)
@@ -183,10 +190,10 @@ def test_full_size_unet_fused_feed_forward_paths_agree():
         # per output element, so switching the split off (knob 1024) must not change a bit - residuals, time-embedding bias and all
         try:
             eng.set_ff_fused(False, prenorm=False)
-            eng.lib.ug_tune_force(-100 - 1024, 0)
+            eng.tune_force(-100 - 1024, 0)
             nosplit = eng.unet_forward(x, 1.2, emb)
         finally:
-            eng.lib.ug_tune_force(-100, 0)
+            eng.tune_force(-100, 0)
             eng.set_ff_fused(True, prenorm=True)
         assert np.array_equal(nosplit, ref), "row-split 3x3 convolutions are not bit-identical to single launches"
         assert_close(outs["fused + in-kernel LayerNorm"], ref, 4e-3, "full-size UNet forward, in-kernel LayerNorm vs LayerNorm launches")

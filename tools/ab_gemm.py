@@ -38,14 +38,14 @@ def ab(label, **kw):
     for rnd in range(3):
         for v in VARS:
             cfg, kn = parse(v)
-            eng.lib.ug_tune_force(-100 - kn, 0)
+            eng.tune_force(-100 - kn, 0)
             try:
                 ms, tf, c, s = eng.bench_gemm(cfg=cfg, split=(0 if cfg < 0 else 1), iters=10, **kw)
             except RuntimeError:
                 continue
             key = f"{v}(c{c}/s{s})" if cfg < 0 else v
             best[key] = max(best.get(key, 0), tf)
-    eng.lib.ug_tune_force(-100, 0)
+    eng.tune_force(-100, 0)
     print(f"{label:22s} " + "  ".join(f"{k}:{v:6.0f}" for k, v in best.items()), flush=True)
 
 

@@ -10,8 +10,8 @@ dense = [(76800, 2560, 320), (76800, 320, 1280), (19200, 5120, 640), (19200, 640
 for (M, N, K) in dense:
     row = []
     for knob in (32, 0, 32, 0):
-        eng.lib.ug_tune_force(-100 - knob, 0)
+        eng.tune_force(-100 - knob, 0)
         ms, tf, c, s = eng.bench_gemm(M, N, K, iters=20)
         row.append(f"{'row-major' if knob else 'grouped  '} {ms * 1e3:7.1f} us {tf:5.0f} TF/s")
     print(f"{M:6d}x{N:5d}x{K:5d} cfg {c:2d}: " + " | ".join(row), flush=True)
-eng.lib.ug_tune_force(-100, 0)
+eng.tune_force(-100, 0)

@@ -22,8 +22,8 @@ convs = [("unet320@48x64", 320, dict(T=25, H=48, W=64, C0=320, C1=0, kt=1, k=3))
 for name, N, cv in convs:
     row = []
     for knob in (128, 0, 128, 0):
-        eng.lib.ug_tune_force(-100 - knob, 0)
+        eng.tune_force(-100 - knob, 0)
         ms, tf, c, s = eng.bench_gemm(N=N, conv=cv, iters=20)
         row.append(f"{'tap-major  ' if knob else 'chunk-major'} {ms * 1e3:7.1f} us {tf:5.0f} TF/s")
     print(f"{name:20s} cfg {c:2d} split {s}: " + " | ".join(row), flush=True)
-eng.lib.ug_tune_force(-100, 0)
+eng.tune_force(-100, 0)

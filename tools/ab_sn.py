@@ -13,7 +13,7 @@ lib = pred.engine.lib
 for _ in range(3): pred.predict_batch(x)
 for r in range(reps):
     for off in (1, 0):
-        lib.ug_tune_force(-100 - (knob if off else 0), 0)
+        pred.engine.tune_force(-100 - (knob if off else 0), 0)
         pred.predict_batch(x)
         t0 = time.perf_counter()
         for _ in range(5): pred.predict_batch(x)

@@ -22,8 +22,8 @@ eng.set_inputs(frames, nl, na, np.stack(clip["intrinsics"], 0))
 eng.run(1, 8)
 res = {}
 for c in [-1] + cfgs:
-    eng.lib.ug_tune_force(-100 - knobs, 0)
-    eng.lib.ug_tune_force(c, 1 if c >= 0 else -1)
+    eng.tune_force(-100 - knobs, 0)
+    eng.tune_force(c, 1 if c >= 0 else -1)
     eng.run(1, 8)
     eng.profile_begin(shapes=True)
     eng.run(steps, 8)
@@ -31,7 +31,7 @@ for c in [-1] + cfgs:
     for k, v in prof.items():
         if k.startswith("gemm_"):
             res.setdefault(k, {})[c] = (v["ms"] * 1000 / v["calls"], v["calls"], v["flops"] / v["calls"])
-eng.lib.ug_tune_force(-1, -1)
+eng.tune_force(-1, -1)
 rows = sorted(res.items(), key=lambda kv: -kv[1][-1][0] * kv[1][-1][1])
 print("shape".ljust(44) + "calls  " + "  ".join(f"{'plan' if c < 0 else 'c%d' % c:>8s}" for c in [-1] + cfgs) + "   best")
 for k, d in rows[:60]:

@@ -6,7 +6,7 @@ from unigeo_amd._lib import Engine
 
 eng = Engine(0, workspace_bytes=24 << 30, persist_bytes=64 << 20)
 if os.environ.get('UG_KNOBS'):
-    eng.lib.ug_tune_force(-100 - int(os.environ['UG_KNOBS']), 0)
+    eng.tune_force(-100 - int(os.environ['UG_KNOBS']), 0)
 CFG = {0: "128x128x64s2", 1: "128x64x64s2", 2: "128x128x64s3", 3: "128x64x64s3", 4: "256x128x64s3", 5: "128x128x32s4",
        6: "256x256x32s3", 7: "256x128x32s4", 8: "256x128x64s2", 9: "128x128x32s3",
        10: "128x64x32s2", 11: "128x64x32s4", 12: "64x64x64s2", 13: "64x128x64s2", 14: "256x64x64s2", 15: "256x256x64s2(2x4)", 16: "256x256x64s2(4x2)", 17: "256x256x32s4", 18: "256x256x32s3", 19: "256x128x64s3(2x4)", 20: "256x128x32s2(4w)", 21: "128x256x32s2(4w)", 22: "256x128x32s3(4w)"}

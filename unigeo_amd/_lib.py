@@ -22,7 +22,7 @@ EXPORTS = [
     "ug_eval_depth", "ug_eval_normal", "ug_clip_embed", "ug_vae_encode", "ug_vae_decode", "ug_unet_forward", "ug_normals_from_depth",
     "ug_op_linear", "ug_op_conv", "ug_op_groupnorm", "ug_op_layernorm", "ug_op_flash_attn",
     "ug_op_temporal_attn", "ug_op_attention_generic", "ug_op_euler_step",
-    "ug_bind_stablenormal", "ug_sn_run", "ug_sn_unet_forward", "ug_sn_dino", "ug_sn_vae_decode", "ug_sn_vae_encode",
+    "ug_bind_stablenormal", "ug_sn_run", "ug_sn_unet_forward", "ug_sn_dino", "ug_sn_vae_decode", "ug_sn_vae_encode", "ug_resize_bilinear",
     "ug_profile_begin", "ug_profile_begin_shapes", "ug_profile_end", "ug_bench_gemm", "ug_bench_groupnorm", "ug_tune_force",
 ]
 
@@ -116,10 +116,11 @@ def load_library():
     lib.ug_sn_dino.argtypes = [vp, vp, ip, ip, ip, vp]
     lib.ug_sn_vae_decode.argtypes = [vp, vp, ip, ip, ip, vp]
     lib.ug_sn_vae_encode.argtypes = [vp, vp, ip, ip, ip, vp]
+    lib.ug_resize_bilinear.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, ip, vp]
     lib.ug_profile_begin.argtypes = [vp]
     lib.ug_bench_gemm.argtypes = [vp] + [ip] * 16 + [vp]
     lib.ug_bench_groupnorm.argtypes = [vp, ip, ip, ip, ip, ip, ip, ip, vp]
-    lib.ug_tune_force.argtypes = [ip, ip]
+    lib.ug_tune_force.argtypes = [vp, ip, ip]
     lib.ug_profile_begin_shapes.argtypes = [vp]
     lib.ug_profile_end.restype = C.c_char_p
     lib.ug_profile_end.argtypes = [vp]
@@ -262,6 +263,13 @@ class Engine:
         self._ck(self.lib.ug_sn_vae_decode(self.ctx, _ptr(z), B, h, w, _ptr(out)))
         return out
 
+    def resize_bilinear(self, x_bhwc, Ho, Wo, normalise=False):
+        """torch F.interpolate(mode="bilinear", antialias=True, align_corners=False) on the device; [B,Hi,Wi,C<=4] f32 -> [B,Ho,Wo,C]."""
+        x = _f32(x_bhwc); B, Hi, Wi, Cc = x.shape
+        out = np.empty((B, int(Ho), int(Wo), Cc), np.float32)
+        self._ck(self.lib.ug_resize_bilinear(self.ctx, _ptr(x), B, Hi, Wi, Cc, int(Ho), int(Wo), int(bool(normalise)), _ptr(out)))
+        return out
+
     def sn_vae_encode(self, img_m11):
         f = _f32(img_m11); B, H, W, _ = f.shape
         out = np.empty((B, 4, H // 8, W // 8), np.float32)
@@ -283,7 +291,7 @@ class Engine:
         else:
             self._ck(self.lib.ug_dc_run(self.ctx, int(steps), int(decode_chunk), int(bool(with_normals))))
 
-    def set_concurrency(self, lanes=3):
+    def set_concurrency(self, lanes=2):
         """Independent chunks (VAE encode / decode chunks, CLIP tower) in flight on separate HIP streams; 1 = serial.  Bit-identical outputs."""
         self._ck(self.lib.ug_set_concurrency(self.ctx, int(lanes)))
 
@@ -479,6 +487,10 @@ class Engine:
                                         cv.get("ups", 1), cfg, split, iters, _ptr(out)))
         Mr, Kr = float(out[3]), float(out[4])
         return float(out[0]), 2.0 * Mr * N * Kr / (out[0] * 1e-3) / 1e12, int(out[1]), int(out[2])
+
+    def tune_force(self, cfg=-1, split=-1):
+        """Test / A-B aid, per context: force a GEMM tile config + split-K factor ((-1, -1) = planner); cfg = -100 - mask sets the knob mask."""
+        self._ck(self.lib.ug_tune_force(self.ctx, int(cfg), int(split)))
 
     def bench_groupnorm(self, C0, C1, T, HW, temporal, mode, iters=20):
         out = np.zeros(1, np.float32)

@@ -360,6 +360,19 @@ int ug_normals_from_depth(ug_ctx* x, const float* depth, const float* K, int T, 
   });
 }
 
+int ug_resize_bilinear(ug_ctx* x, const float* in, int B, int Hi, int Wi, int C, int Ho, int Wo, int normalise, float* out) {
+  UG_TRY(x, {
+    Ctx& c = x->c; Scope sc(c);
+    UG_REQUIRE(B >= 1 && Hi >= 1 && Wi >= 1 && Ho >= 1 && Wo >= 1 && C >= 1 && C <= 4, "resize shape");
+    const long ni = (long)B * Hi * Wi * C, no = (long)B * Ho * Wo * C;
+    float* di = c.ws.get<float>(ni); float* dout = c.ws.get<float>(no);
+    UG_CHECK(hipMemcpyAsync(di, in, ni * 4, hipMemcpyHostToDevice, c.stream));
+    launch_resize_bilinear_aa(di, dout, B, Hi, Wi, Ho, Wo, C, normalise, c.stream);
+    UG_CHECK(hipMemcpyAsync(out, dout, no * 4, hipMemcpyDeviceToHost, c.stream));
+    UG_CHECK(hipStreamSynchronize(c.stream));
+  });
+}
+
 int ug_eval_depth(ug_ctx* x, const float* pred, const float* gt, const unsigned char* cmask, long n, float max_depth, double* out) {
   UG_TRY(x, {
     Ctx& c = x->c; Scope sc(c);
@@ -469,6 +482,7 @@ int ug_op_linear(ug_ctx* x, const float* A, int M, int K, const float* W, int N,
     GemmP p; memset(&p, 0, sizeof(p));
     p.A0 = dA; p.C0 = K; p.M = M; p.N = N; p.K = K; p.W = dW; p.ldw = K; p.bias = db; p.R1 = dR; p.ldr1 = Nout;
     p.c0 = c0; p.c1 = c1; p.act = act; p.flags = geglu ? UG_F_GEGLU : 0; p.Out = dO; p.ldo = Nout; p.zero = c.zero; p.nb_inner = 1;
+    gemm_apply_tune(p, c.tune);
     { int cf, sp; gemm_plan(p, 1, &cf, &sp); p.cfg_p1 = cf + 1; p.splitk = sp; if (sp > 1) p.partial = c.ws.get<float>((long)sp * M * N); }
     launch_gemm(p, 1, c.stream);
     down16(c, dO, out, (long)M * Nout);
@@ -512,11 +526,11 @@ int ug_op_ln_ff(ug_ctx* x, const float* X, int M, int C, const float* gamma, con
         GemmP g1; memset(&g1, 0, sizeof(g1));
         g1.A0 = t1; g1.C0 = C; g1.M = M; g1.N = 2 * I; g1.K = C; g1.W = dW1; g1.ldw = C; g1.bias = db1; g1.c0 = 1.f; g1.Out = mid; g1.ldo = I;
         g1.flags = UG_F_GEGLU; g1.zero = c.zero; g1.nb_inner = 1;
-        launch_gemm(g1, 1, c.stream);
+        gemm_apply_tune(g1, c.tune); launch_gemm(g1, 1, c.stream);
         GemmP g2; memset(&g2, 0, sizeof(g2));
         g2.A0 = mid; g2.C0 = I; g2.M = M; g2.N = C; g2.K = I; g2.W = dW2; g2.ldw = I; g2.bias = db2; g2.c0 = c0; g2.R1 = res; g2.ldr1 = C; g2.c1 = c1;
         g2.Out = dO; g2.ldo = C; g2.zero = c.zero; g2.nb_inner = 1; g2.splitk = 1;
-        launch_gemm(g2, 1, c.stream);
+        gemm_apply_tune(g2, c.tune); launch_gemm(g2, 1, c.stream);
       }
     }
     down16(c, dO, out, (long)M * C);
@@ -547,11 +561,11 @@ int ug_op_ff(ug_ctx* x, const float* X, int M, int C, const float* W1, const flo
       GemmP g1; memset(&g1, 0, sizeof(g1));
       g1.A0 = dX; g1.C0 = C; g1.M = M; g1.N = 2 * I; g1.K = C; g1.W = dW1; g1.ldw = C; g1.bias = db1; g1.c0 = 1.f; g1.Out = mid; g1.ldo = I;
       g1.flags = UG_F_GEGLU; g1.zero = c.zero; g1.nb_inner = 1;
-      launch_gemm(g1, 1, c.stream);
+      gemm_apply_tune(g1, c.tune); launch_gemm(g1, 1, c.stream);
       GemmP g2; memset(&g2, 0, sizeof(g2));
       g2.A0 = mid; g2.C0 = I; g2.M = M; g2.N = C; g2.K = I; g2.W = dW2; g2.ldw = I; g2.bias = db2; g2.c0 = c0; g2.R1 = dR; g2.ldr1 = C; g2.c1 = c1;
       g2.Out = dO; g2.ldo = C; g2.zero = c.zero; g2.nb_inner = 1; g2.splitk = 1;
-      launch_gemm(g2, 1, c.stream);
+      gemm_apply_tune(g2, c.tune); launch_gemm(g2, 1, c.stream);
     }
     down16(c, dO, out, (long)M * C);
   });
@@ -594,11 +608,11 @@ int ug_bench_ff(ug_ctx* x, int M, int C, int fused, int iters, float* us_out) {
         GemmP g1; memset(&g1, 0, sizeof(g1));
         g1.A0 = dX; g1.C0 = C; g1.M = M; g1.N = 2 * I; g1.K = C; g1.W = dW1; g1.ldw = C; g1.bias = db1; g1.c0 = 1.f; g1.Out = mid; g1.ldo = I;
         g1.flags = UG_F_GEGLU; g1.zero = c.zero; g1.nb_inner = 1;
-        launch_gemm(g1, 1, c.stream);
+        gemm_apply_tune(g1, c.tune); launch_gemm(g1, 1, c.stream);
         GemmP g2; memset(&g2, 0, sizeof(g2));
         g2.A0 = mid; g2.C0 = I; g2.M = M; g2.N = C; g2.K = I; g2.W = dW2; g2.ldw = I; g2.bias = db2; g2.c0 = 1.f; g2.R1 = dR; g2.ldr1 = C; g2.c1 = 1.f;
         g2.Out = dO; g2.ldo = C; g2.zero = c.zero; g2.nb_inner = 1; g2.splitk = 1;
-        launch_gemm(g2, 1, c.stream);
+        gemm_apply_tune(g2, c.tune); launch_gemm(g2, 1, c.stream);
       }
     };
     run(); run();
@@ -644,6 +658,7 @@ int ug_op_linear_mx8(ug_ctx* x, const float* A, int M, int K, const float* W, in
     p.A0 = (const f16*)a8; p.C0 = K; p.M = M; p.N = N; p.K = K; p.W = (const f16*)w8; p.ldw = K; p.bias = db; p.c0 = 1.f;
     p.Out = dO; p.ldo = nout; p.flags = geglu ? UG_F_GEGLU : 0; p.zero = c.zero; p.nb_inner = 1;
     p.sa = sa; p.ld_sa = ld_sa; p.sw = sw; p.ld_sw = ld_sw;
+    gemm_apply_tune(p, c.tune);
     launch_gemm_mx8(p, c.stream);
     down16(c, dO, out, (long)M * nout);
     if (a8_out) UG_CHECK(hipMemcpy(a8_out, a8, (size_t)M * K, hipMemcpyDeviceToHost));
@@ -670,6 +685,7 @@ int ug_op_conv(ug_ctx* x, const float* x0, int C0, const float* x1, int C1, int 
     p.ups = ups; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l; p.kt = kt; p.ky = k; p.kx = k;
     p.M = T * Ho * Wo; p.N = O; p.K = I * taps; p.W = dW; p.ldw = p.K; p.bias = db; p.c0 = 1.f;
     p.Out = dO; p.ldo = O; p.zero = c.zero; p.nb_inner = 1; p.kchunk = kch;
+    gemm_apply_tune(p, c.tune);
     { int cf, sp; gemm_plan(p, 1, &cf, &sp); p.cfg_p1 = cf + 1; p.splitk = sp; if (sp > 1) p.partial = c.ws.get<float>((long)sp * p.M * p.N); }
     launch_gemm(p, 1, c.stream);
     down16(c, dO, out, (long)T * Ho * Wo * O);
@@ -768,7 +784,12 @@ int ug_op_attention_generic(ug_ctx* x, const float* qkv, int B, int S, int H, in
   });
 }
 
-int ug_tune_force(int cfg, int split) { gemm_force(cfg, split); return 0; }
+int ug_tune_force(ug_ctx* x, int cfg, int split) {
+  if (!x) return -1;
+  if (cfg <= -100) x->c.tune.knobs = -cfg - 100;             // knob mask: ug_tune_force(ctx, -100 - knobs, 0)
+  else { x->c.tune.cfg = cfg; x->c.tune.split = split; }
+  return 0;
+}
 int ug_tune_flash(int variant) { flash_set_variant(variant); return 0; }
 
 // GEMM / conv microbenchmark on device-resident pseudo-random data: average ms per launch over `iters`.
@@ -803,6 +824,7 @@ int ug_bench_gemm(ug_ctx* x, int M, int N, int K, int conv, int T, int Hi, int W
     p.A0 = As[0]; p.A1 = A1s[0]; p.Out = Os[0];
     if (getenv("UG_BENCH_GEGLU") && !conv && N % 128 == 0) { p.flags |= UG_F_GEGLU; p.ldo = N / 2; }   // A/B aid: GEGLU epilogue
     if (getenv("UG_BENCH_R1")) { p.R1 = Os[nbuf - 1]; p.ldr1 = N; p.c1 = 1.f; }                          // A/B aid: a residual operand in the epilogue
+    gemm_apply_tune(p, c.tune);
     int cf = cfg, sp = split;
     if (cf < 0 || sp < 1) { int c2, s2; gemm_plan(p, 1, &c2, &s2); if (cf < 0) cf = c2; if (sp < 1) sp = s2; }
     p.cfg_p1 = cf + 1; p.splitk = sp;

@@ -78,14 +78,17 @@ struct GemmP {
   int m_off;             // im2col only, producer / consumer kernel only: this launch covers output rows [m_off, m_off + M) of the convolution
                          // (Out / R1 / R2 already point at row m_off) - row-split launches, see launch_gemm
   int group_m;           // tile walk: 0 / 1 = row-major, g > 1 = g M-tiles x all N tiles column by column (set by launch_gemm; see tile_coord)
+  int tune_cfg_p1, tune_split_p1, tune_knobs;   // GemmTune of the launching context, + 1 so that a zeroed GemmP means "no override"
 };
+// tuning overrides (A/B tools and the tile-config tests; ug_tune_force sets them on ONE context, the engine copies them into every GemmP):
+// cfg / split -1 = planner's choice; knobs = bit mask documented in kernels/gemm.hip
+struct GemmTune { int cfg = -1, split = -1, knobs = 0; };
+static inline void gemm_apply_tune(GemmP& p, const GemmTune& t) { p.tune_cfg_p1 = t.cfg + 1; p.tune_split_p1 = t.split + 1; p.tune_knobs = t.knobs; }
 void launch_gemm_mx8(const GemmP& p, hipStream_t s);   // dense only; C0 = lda and ldw in BYTES (= elements)
 // fp16 [M, K] (row stride ldx) -> e4m3 bytes [M, K] + e8m0 scales (layout above, ld_s >= round_up(M, 256)); K % 128 == 0
 void launch_quant_mx8(const f16* x, long ldx, long M, int K, unsigned char* q, unsigned* scales, long ld_s, hipStream_t s);
 void launch_gemm(const GemmP& p, int batch, hipStream_t s);
 void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out);   // heuristic used when cfg/splitk are 0
-void gemm_force(int cfg, int split);
-int gemm_knobs_get();                                       // tuning aid: override the heuristic (-1 = off)
 
 // Fused GEGLU feed-forward (kernels/ff_fused.hip): Out = c0 * (GEGLU(X W1^T + b1) W2^T + b2) + c1 R1 + c2 R2, all [M, C] row-major (ld = C);
 // W1 [8C][C] / b1 [8C] in the bound GEGLU row order (blocks of 16 rows = [8 value | 8 gate]), W2 [C][4C], C in {64,...,320}
@@ -189,7 +192,8 @@ void launch_clip_patchify(const f16* video_m11, f16* patches, int T, int H, int 
                           int P, int Kpad, hipStream_t s, int imagenet_norm = 0);   // 0: CLIP mean/std, 1: ImageNet mean/std (DINOv2)
 void launch_scale_rows(f16* w, const f16* gamma, int N, int K, hipStream_t s);     // w[n][:] *= gamma[n] (LayerScale folded into a projection)
 void launch_add_grid_nearest(f16* x, const f16* grid, int B, int h, int w, int g, int C, hipStream_t s);   // x[b,y,x,:] += grid[b, y*g/h, x*g/w, :]
-void launch_sn_normals_out(const f16* dec, int ldd, float* out, long pixels, hipStream_t s);   // clip to [-1,1], L2-normalise -> f32 [pixels,3]
+void launch_sn_normals_out(const f16* dec, int ldd, float* out, long pixels, hipStream_t s);
+void launch_resize_bilinear_aa(const float* in, float* out, int B, int Hi, int Wi, int Ho, int Wo, int C, int normalise, hipStream_t s);   // torch antialias bilinear   // clip to [-1,1], L2-normalise -> f32 [pixels,3]
 void launch_init_latents2(const float* noise, f16* lat, float sigma0, int T, long hw, hipStream_t s);
 void launch_silu_f16(const f16* in, f16* out, long n, hipStream_t s);
 void launch_clip_assemble(const f16* patches, const f16* cls, const f16* pos, f16* tok, int T, int np, int d,

@@ -163,8 +163,11 @@ struct Ctx {
   int vae_encode_fp32 = 1;   // 1 = reference behaviour (float32-grade encoder), 0 = fp16 storage like the decoder
   // lanes (run_lanes): streams are created on first use; lane_need remembers the arena bytes a task kind needed when it first ran serially
   std::vector<Lane> lanes; hipEvent_t fork_ev = nullptr;
-  int concurrency = 3;       // independent sub-graphs in flight (1 = everything on the one stream, in order); outputs are bit-identical
+  int concurrency = 1;       // independent sub-graphs in flight (1 = everything on the one stream, in order; ug_set_concurrency); outputs are
+                             // bit-identical.  Measured on the 25 x 384 x 512 clip: 2 lanes -0.6 %, 3 lanes +-0 - the persistent GEMMs fill the
+                             // register file of every CU, so a second stream's kernels only get the tail rounds
   std::map<std::string, size_t> lane_need;
+  GemmTune tune;             // ug_tune_force: tile-config / split-K / knob overrides for THIS context's GEMM launches (tests, A/B tools)
 };
 
 void* pinned(Ctx& c, int slot, size_t bytes);   // page-locked staging buffer of at least `bytes`

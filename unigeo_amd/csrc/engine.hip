@@ -59,6 +59,14 @@ struct RunGuard {
 // lanes, each with a private arena slice of the recorded size, forked from / joined to the main stream with events.  The kernels and
 // their launch parameters are the same either way, so outputs are bit-identical (tests/test_pipeline_gpu.py).  Event-bracketed
 // profiling passes (c.prof_on) stay serial so that every kernel is timed alone.
+// Lanes that run the same kernel sequence start in lockstep and stay there (the dispatcher arbitrates the queues symmetrically), so all of them
+// sit in their HBM-bound passes at the same time and in their MFMA-bound ones at the same time - measured: no gain at all.  A one-wave
+// kernel that sleeps for ~us microseconds at the head of lane l breaks the symmetry.
+__global__ void k_lane_stagger(int us) {
+  const long long t0 = wall_clock64();                 // 100 MHz constant clock
+  while (wall_clock64() - t0 < (long long)us * 100) __builtin_amdgcn_s_sleep(64);
+}
+
 template <class Kind, class Body>
 static void run_lanes(Ctx& c, int ntask, Kind kind, Body body) {
   std::vector<size_t> need(ntask, 0);
@@ -94,7 +102,12 @@ static void run_lanes(Ctx& c, int ntask, Kind kind, Body body) {
   hipStream_t main_stream = c.stream;
   Arena main_ws = c.ws;
   UG_CHECK(hipEventRecord(c.fork_ev, main_stream));
-  for (int l = 0; l < nl; ++l) UG_CHECK(hipStreamWaitEvent(c.lanes[l].stream, c.fork_ev, 0));
+  static const int stagger_us = getenv("UG_LANE_STAGGER") ? atoi(getenv("UG_LANE_STAGGER")) : 1500;
+  for (int l = 0; l < nl; ++l) {
+    UG_CHECK(hipStreamWaitEvent(c.lanes[l].stream, c.fork_ev, 0));
+    if (l > 0 && stagger_us > 0) hipLaunchKernelGGL(k_lane_stagger, dim3(1), dim3(64), 0, c.lanes[l].stream, l * stagger_us);
+  }
+  if (getenv("UG_LANE_DEBUG")) fprintf(stderr, "[ug] run_lanes: %d tasks on %d lanes, slice %.2f GB (%s ...)\n", ntask, nl, slice / 1073741824.0, kind(0).c_str());
   // longest task first, each to the lane with the least work so far (need is a fair proxy for a chunk's cost)
   std::vector<int> order(ntask); for (int i = 0; i < ntask; ++i) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return need[a] > need[b]; });
@@ -188,6 +201,7 @@ struct Epi {
 
 static void run_gemm(Ctx& c, GemmP p, int batch, const char* tag, float alg = 1.f) {
   p.zero = c.zero;
+  gemm_apply_tune(p, c.tune);
   if (p.nb_inner < 1) p.nb_inner = 1;
   char nm[128];
   if (c.prof_on && c.prof_shapes) snprintf(nm, sizeof(nm), "%s:%dx%dx%d%s", tag, p.M, p.N, p.K, batch > 1 ? "b" : "");
@@ -253,6 +267,7 @@ static void linear(Ctx& c, const f16* A, long M, const Lin& l, f16* out, const E
     if (p.R1 && !p.ldr1) p.ldr1 = nout;
     if (p.R2 && !p.ldr2) p.ldr2 = nout;
     p.sa = sa; p.ld_sa = ld_sa; p.sw = l.sw8; p.ld_sw = l.ld_sw8; p.zero = c.zero; p.nb_inner = 1;
+    gemm_apply_tune(p, c.tune);
     {
       ProfScope ps(c, nmg, 2.0 * M * (double)l.out * K, (double)M * K + (double)l.out * K + 2.0 * M * nout);
       launch_gemm_mx8(p, c.stream);

@@ -1197,7 +1197,6 @@ __global__ __launch_bounds__(256) void splitk_epilogue(const GemmP p) {
   }
 }
 
-int gemm_knobs_get();
 template <int BM, int BN, int BK, int NST, int WMW, int WNW, bool CONV, bool UNI, bool BUFA = false>
 static void launch_t(const GemmP& p, int batch, hipStream_t s) {
   const int ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
@@ -1220,7 +1219,7 @@ static void launch_t(const GemmP& p, int batch, hipStream_t s) {
   int gx = (cap / 8) * 8;                  // a multiple of 8 keeps the XCD-aware tile walk
   gx = std::min(gx, ntiles);
   if (gx < ntiles && cap >= ntiles) gx = ntiles;   // ... unless rounding down would push a few tiles into a second round (100 tiles, 5 K slices: 102 -> 96)
-  if (gemm_knobs_get() & 1) gx = ntiles;
+  if (p.tune_knobs & 1) gx = ntiles;
   dim3 grid(gx, split, batch);
   hipLaunchKernelGGL(kern, grid, dim3(WMW * WNW * 64), lds, s, p);
 }
@@ -1229,7 +1228,7 @@ template <int BM, int BN, int BK, int NST, int WMW, int WNW>
 static void launch_mode(const GemmP& p, int batch, hipStream_t s) {
   UG_REQUIRE(p.m_off == 0, "row-split launches need the producer / consumer kernel");
   const long lim = (1L << 31) - 64;   // buffer addressing: every byte offset must stay below num_records
-  const bool bufw = (long)p.N * p.ldw * 2 < lim && !(gemm_knobs_get() & 4);
+  const bool bufw = (long)p.N * p.ldw * 2 < lim && !(p.tune_knobs & 4);
   if (p.conv) {
     // the single-tap-per-K-tile paths walk K chunk-major: the weights must be laid out that way (trivially true for 1 tap / 1 chunk)
     const bool kc_ok = p.kchunk || p.kt * p.ky * p.kx == 1 || (p.C0 + p.C1) == BK;
@@ -1241,7 +1240,7 @@ static void launch_mode(const GemmP& p, int batch, hipStream_t s) {
     else launch_t<BM, BN, BK, NST, WMW, WNW, true, false>(p, batch, s);
   } else {
     // dense: measured +4-6 % on the 8-wave tiles, -1..-4 % on the 4-wave 128x64 / 256x64 ones (profiles/r01_gemm_buffer_addressing.txt)
-    const bool bufa = bufw && p.K % BK == 0 && (long)p.M * p.C0 * 2 < lim && (BM * BN >= 256 * 128 || (gemm_knobs_get() & 8));
+    const bool bufa = bufw && p.K % BK == 0 && (long)p.M * p.C0 * 2 < lim && (BM * BN >= 256 * 128 || (p.tune_knobs & 8));
     if (bufa) launch_t<BM, BN, BK, NST, WMW, WNW, false, false, true>(p, batch, s);
     else launch_t<BM, BN, BK, NST, WMW, WNW, false, false>(p, batch, s);
   }
@@ -1279,7 +1278,7 @@ static void launch_cfg(int cfg, const GemmP& p, int batch, hipStream_t s) {
   }
 }
 
-static int g_force_cfg = -1, g_force_split = -1, g_knobs = 0;   // knobs: 1 = one tile per workgroup, 2 = no XCD remap, 4 = flat addressing only
+// tuning overrides travel with the problem (GemmP::tune_*; the engine copies its context's - ug_tune_force): knobs 1 = one tile per workgroup, 2 = no XCD remap, 4 = flat addressing only
 // ---- MX-fp8 dense GEMM (BASELINE configs[4]): the same persistent kernel on e4m3 operands with e8m0 block scales ----
 template <int BM, int BN, int NST, int WMW, int WNW, bool BUFA>
 static void launch_mx_t(const GemmP& p, hipStream_t s) {
@@ -1309,8 +1308,8 @@ void launch_gemm_mx8(const GemmP& p0, hipStream_t s) {
   if (p.flags & UG_F_GEGLU) UG_REQUIRE(p.N % 128 == 0, "GEGLU GEMM needs N % 128 == 0");
   p.K /= 2; p.C0 /= 2; p.ldw /= 2;          // bytes -> the loaders' fp16 units (see gemm_kernel<MX>)
   p.splitk = 1; p.cfg_p1 = 0;
-  if (g_knobs & 2) p.flags |= UG_F_NOXCD;
-  const int force = g_force_cfg;
+  if (p.tune_knobs & 2) p.flags |= UG_F_NOXCD;
+  const int force = (p.tune_cfg_p1 - 1);
   // largest tile that still gives the 256 CUs ~one workgroup each (profiles/r02_mx8_per_shape.txt: 4800x1280x5120 on 256x256 tiles = 95
   // workgroups ran below the fp16 kernel)
   const long t256 = (long)cdiv(p.M, 256) * cdiv(p.N, 256), t128n = (long)cdiv(p.M, 256) * cdiv(p.N, 128);
@@ -1329,7 +1328,7 @@ void launch_gemm_mx8(const GemmP& p0, hipStream_t s) {
     const int bm = pick == 2 ? 128 : pick == 3 ? 192 : 256, bn = pick == 0 ? 256 : 128, percu = pick == 2 ? 2 : 1;
     const int ntm = cdiv(p.M, bm), ntn = cdiv(p.N, bn);
     int g = 1;
-    if (!(g_knobs & 32) && (double)p.N * p.K * 2.0 > 3.0 * (1 << 20) && ntm >= 2 && ntn >= 2)
+    if (!(p.tune_knobs & 32) && (double)p.N * p.K * 2.0 > 3.0 * (1 << 20) && ntm >= 2 && ntn >= 2)
       while (g * 2 <= ntm && (double)(g * 2) * (g * 2) <= 32.0 * percu * bn / bm * 1.5) g *= 2;
     p.group_m = g;
   }
@@ -1342,11 +1341,9 @@ void launch_gemm_mx8(const GemmP& p0, hipStream_t s) {
   UG_CHECK(hipGetLastError());
 }
 
-void gemm_force(int cfg, int split) { if (cfg <= -100) { g_knobs = -cfg - 100; return; } g_force_cfg = cfg; g_force_split = split; }
 
 
 
-int gemm_knobs_get() { return g_knobs; }
 
 // Tile planner.  For every candidate tile the attainable rate is modelled as
 //     base(cfg) x (M, N edge-tile utilisation) x (fill of the last round of the persistent grid)
@@ -1413,7 +1410,7 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
         if (sp >= 2) { cfg = 3; split = sp; }
       }
     }
-  } else if (!(g_knobs & 512) && plain_epi && p.M <= 8192 && tiles128 <= 256 && p.N >= 128 && p.N < 2048 && (p.conv ? nk >= 32 : nk >= 16)) {
+  } else if (!(p.tune_knobs & 512) && plain_epi && p.M <= 8192 && tiles128 <= 256 && p.N >= 128 && p.N < 2048 && (p.conv ? nk >= 32 : nk >= 16)) {
     // Under-filled launch (a 72x72 / 36x36 latent of ONE image: 40 - 250 tiles of 128x128 for 256 CUs): the cost model above prices a
     // round by its tile size only and keeps the 256x128 tile on 63 workgroups; what helps is workgroups - 128x128 (im2col) or 128x64
     // (dense) tiles, K sliced until ~512 are in flight (knob 512 = off; tools/ab_sn.py)
@@ -1432,15 +1429,15 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
   }
   // (a former rule - four K slices of the 128x128 tile for the 12x16 level's concatenated 2560-channel convs, 880 TFLOP/s - is gone:
   // the 192-row tile fills the chip there without split-K, 236 vs 324 us = 1200 TFLOP/s)
-  if (g_force_cfg >= 0 && !(geglu && g_force_cfg != 0 && g_force_cfg != 4 && g_force_cfg != 8 && g_force_cfg != 15 && g_force_cfg != 35 && g_force_cfg != 54 && g_force_cfg != 62 && g_force_cfg != 64)) cfg = g_force_cfg;
-  if (g_force_split >= 0) split = plain_epi ? std::max(1, g_force_split) : 1;
+  if ((p.tune_cfg_p1 - 1) >= 0 && !(geglu && (p.tune_cfg_p1 - 1) != 0 && (p.tune_cfg_p1 - 1) != 4 && (p.tune_cfg_p1 - 1) != 8 && (p.tune_cfg_p1 - 1) != 15 && (p.tune_cfg_p1 - 1) != 35 && (p.tune_cfg_p1 - 1) != 54 && (p.tune_cfg_p1 - 1) != 62 && (p.tune_cfg_p1 - 1) != 64)) cfg = (p.tune_cfg_p1 - 1);
+  if ((p.tune_split_p1 - 1) >= 0) split = plain_epi ? std::max(1, (p.tune_split_p1 - 1)) : 1;
   *cfg_out = cfg; *split_out = split;
 }
 
 // Tile-walk grouping for dense layers whose weights do not fit the per-XCD L2 (tile_coord): the ~P tiles an XCD processes at a time
 // should touch as few operand panels as possible: a x b = P with a * BM ~ b * BN.
 static int pick_group_m(const GemmP& p, int cfg, int batch, int split) {
-  if ((p.conv && (g_knobs & 64)) || batch > 1 || (g_knobs & 32)) return 1;   // knobs: 32 = row-major walk everywhere, 64 = row-major for im2col (A/B)
+  if ((p.conv && (p.tune_knobs & 64)) || batch > 1 || (p.tune_knobs & 32)) return 1;   // knobs: 32 = row-major walk everywhere, 64 = row-major for im2col (A/B)
   if ((double)p.N * p.K * 2.0 <= 3.0 * (1 << 20)) return 1;          // weights stay L2 resident: share the activation panel instead
   int bm = 256, bn = 128, percu = 1;
   switch (cfg) {
@@ -1463,8 +1460,8 @@ static int pick_group_m(const GemmP& p, int cfg, int batch, int split) {
 
 void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
   GemmP p = p0;
-  if (g_knobs & 2) p.flags |= UG_F_NOXCD;
-  if (g_knobs & 16) p.flags |= UG_F_PRIO;
+  if (p.tune_knobs & 2) p.flags |= UG_F_NOXCD;
+  if (p.tune_knobs & 16) p.flags |= UG_F_PRIO;
   UG_REQUIRE(p.K % 8 == 0, "GEMM K must be a multiple of 8");
   UG_REQUIRE(p.ldw % 8 == 0, "GEMM ldw must be a multiple of 8");
   UG_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "empty GEMM");
@@ -1488,9 +1485,9 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
   // So: the rows of the WHOLE rounds on 256x160 tiles, the remaining rows as a second launch on whatever tile the planner picks for
   // them (tools: 76800 rows, 320 -> 320 channels: 127 + 37 us against 185 - 190 us for any single tiling).  Knob 1024 = off.
   bool planned = p0.cfg_p1 == 0;          // the caller took the planner's choice (run_gemm passes it back explicitly) - not a tuning override
-  if (!planned && g_force_cfg < 0) { int c2, s2; gemm_plan(p0, batch, &c2, &s2); planned = (c2 == cfg && s2 == split); }
+  if (!planned && (p.tune_cfg_p1 - 1) < 0) { int c2, s2; gemm_plan(p0, batch, &c2, &s2); planned = (c2 == cfg && s2 == split); }
   if (planned && p.conv && p.kt == 1 && p.ky == 3 && p.kx == 3 && p.N % 160 == 0 && p.N <= 320 && split == 1 && batch == 1 && !p.up_phase && !(p.flags & (UG_F_OUT_F32 | UG_F_GEGLU)) &&
-      g_force_cfg < 0 && !(g_knobs & 1024) && gemm_can_bufa(p, 64, true)) {
+      (p.tune_cfg_p1 - 1) < 0 && !(p.tune_knobs & 1024) && gemm_can_bufa(p, 64, true)) {
     const long ntn = p.N / 160, tiles = (long)cdiv(p.M, 256) * ntn, whole = tiles / 256 * 256, rem = tiles - whole;
     if (whole > 0 && rem > 0 && rem * 2 <= 256) {
       const int M1 = (int)(whole / ntn) * 256;
@@ -1514,7 +1511,7 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
   if (split > 1) UG_REQUIRE(p.partial != nullptr, "split-K needs a partial buffer");
   p.group_m = pick_group_m(p, cfg, batch, split);
   p.tm_T = p.tm_nb = 0;
-  if (p.conv && p.kt > 1 && p.T > 1 && batch == 1 && !(g_knobs & 256)) {   // knob 256: frame-major M walk for temporal convs (A/B)
+  if (p.conv && p.kt > 1 && p.T > 1 && batch == 1 && !(p.tune_knobs & 256)) {   // knob 256: frame-major M walk for temporal convs (A/B)
     int bm = 256;
     switch (cfg) { case 0: case 1: case 3: bm = 128; break; case 12: bm = 64; break; case 61: case 62: case 63: case 64: bm = 192; break; default: break; }
     const long hw = (long)p.Ho * p.Wo;

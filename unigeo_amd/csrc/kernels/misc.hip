@@ -277,6 +277,48 @@ __global__ void k_sn_normals_out(const f16* dec, int ldd, float* out, long pixel
     for (int c = 0; c < 3; ++c) out[p * 3 + c] = v[c] * inv;
   }
 }
+// Antialiased bilinear resize of a channels-last f32 image batch [B,Hi,Wi,C] -> [B,Ho,Wo,C]: torch's F.interpolate(mode="bilinear",
+// align_corners=False, antialias=True) restated - per axis a triangle filter centred at scale * (o + 0.5) with support max(scale, 1), taps
+// [int(centre - support + 0.5), int(centre + support + 0.5)) clipped to the image, weights normalised (up-sampling: plain bilinear).
+// normalise = 1: L2-normalise the C channels of every output pixel (resizing unit normals back to the input size).
+__global__ void k_resize_bilinear_aa(const float* in, float* out, int B, int Hi, int Wi, int Ho, int Wo, int C, int normalise) {
+  const float sy = (float)Hi / Ho, sx = (float)Wi / Wo;
+  const float supy = sy >= 1.f ? sy : 1.f, supx = sx >= 1.f ? sx : 1.f;
+  const float ivy = sy >= 1.f ? 1.f / sy : 1.f, ivx = sx >= 1.f ? 1.f / sx : 1.f;
+  const long n = (long)B * Ho * Wo;
+  GS_LOOP(idx, n) {
+    const int ox = (int)(idx % Wo); const int oy = (int)((idx / Wo) % Ho); const int b = (int)(idx / ((long)Wo * Ho));
+    const float cy = sy * (oy + 0.5f), cx = sx * (ox + 0.5f);
+    const int y0 = max(0, (int)(cy - supy + 0.5f)), y1 = min(Hi, (int)(cy + supy + 0.5f));
+    const int x0 = max(0, (int)(cx - supx + 0.5f)), x1 = min(Wi, (int)(cx + supx + 0.5f));
+    float wys = 0.f, wxs = 0.f;
+    for (int y = y0; y < y1; ++y) wys += fmaxf(0.f, 1.f - fabsf((y - cy + 0.5f) * ivy));
+    for (int x = x0; x < x1; ++x) wxs += fmaxf(0.f, 1.f - fabsf((x - cx + 0.5f) * ivx));
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int y = y0; y < y1; ++y) {
+      const float wy = fmaxf(0.f, 1.f - fabsf((y - cy + 0.5f) * ivy)) / wys;
+      float row[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int x = x0; x < x1; ++x) {
+        const float wx = fmaxf(0.f, 1.f - fabsf((x - cx + 0.5f) * ivx)) / wxs;
+        const float* px = in + (((long)b * Hi + y) * Wi + x) * C;
+        for (int c = 0; c < C; ++c) row[c] += wx * px[c];
+      }
+      for (int c = 0; c < C; ++c) acc[c] += wy * row[c];
+    }
+    if (normalise) {
+      float q = 0.f;
+      for (int c = 0; c < C; ++c) q += acc[c] * acc[c];
+      const float r = rsqrtf(fmaxf(q, 1e-24f));
+      for (int c = 0; c < C; ++c) acc[c] *= r;
+    }
+    for (int c = 0; c < C; ++c) out[idx * C + c] = acc[c];
+  }
+}
+void launch_resize_bilinear_aa(const float* in, float* out, int B, int Hi, int Wi, int Ho, int Wo, int C, int normalise, hipStream_t s) {
+  UG_REQUIRE(C >= 1 && C <= 4, "resize: 1..4 channels");
+  hipLaunchKernelGGL(k_resize_bilinear_aa, gs_grid((long)B * Ho * Wo), dim3(256), 0, s, in, out, B, Hi, Wi, Ho, Wo, C, normalise);
+}
+
 void launch_sn_normals_out(const f16* dec, int ldd, float* out, long pixels, hipStream_t s) {
   hipLaunchKernelGGL(k_sn_normals_out, gs_grid(pixels), dim3(256), 0, s, dec, ldd, out, pixels);
 }

@@ -35,7 +35,7 @@ class StableNormal:
             warnings.warn(PARITY_NOTE, stacklevel=2)       # said at run time, not only in the docs
             from ..stablenormal import StableNormalPredictorHIP
             from .. import weights as W
-            opts = {k: kwargs[k] for k in ("yoso_timestep", "refine_start", "refine_steps", "prediction_type", "workspace_bytes") if k in kwargs}
+            opts = {k: kwargs[k] for k in ("yoso_timestep", "refine_start", "refine_steps", "prediction_type", "processing_resolution", "workspace_bytes") if k in kwargs}
             model_dir = kwargs.get("model_dir")
             if model_dir and os.path.isdir(model_dir) and os.path.isdir(os.path.join(model_dir, "unet")):
                 self.predictor = StableNormalPredictorHIP.from_pretrained(model_dir, device_id=device_id, **opts)

@@ -66,8 +66,14 @@ class StableNormalPredictorHIP:
 
     parity = "unpinned"      # restated from the published design, never run next to the hub predictor
 
-    def __init__(self, engine, cfgs, prompt_embeds, yoso_timestep=999, refine_start=401, refine_steps=10, prediction_type="v_prediction"):
+    def __init__(self, engine, cfgs, prompt_embeds, yoso_timestep=999, refine_start=401, refine_steps=10, prediction_type="v_prediction",
+                 processing_resolution=0):
         self.engine, self.cfgs = engine, cfgs
+        # 0 (default) = process at the input size (S1).  R > 0: the hub predictor's contract as far as it is publicly described - the image is
+        # resized so that its longer side is R (both sides rounded to multiples of 64, antialiased bilinear, on the device), processed, and the
+        # normals are resized back to the input size and re-normalised.  UNPINNED like the rest of the predictor.
+        self.processing_resolution = int(processing_resolution)
+        self.prediction_type = prediction_type
         self.prompt_embeds = np.ascontiguousarray(prompt_embeds, dtype=np.float32)
         if self.prompt_embeds.shape != (77, cfgs[0].cross_attention_dim):
             raise ValueError(f"prompt_embeds must be [77, {cfgs[0].cross_attention_dim}]")
@@ -105,8 +111,16 @@ class StableNormalPredictorHIP:
         x = np.ascontiguousarray(images01, dtype=np.float32)
         if x.ndim != 4 or x.shape[-1] != 3:
             raise ValueError("images must be [B,H,W,3] float in [0,1]")
-        if x.shape[1] % 64 or x.shape[2] % 64:
-            raise ValueError("height and width must be multiples of 64")
+        H, Wd = x.shape[1:3]
+        R = self.processing_resolution
+        if R > 0:
+            sc = R / float(max(H, Wd))
+            ph, pw = max(64, int(round(H * sc / 64.0)) * 64), max(64, int(round(Wd * sc / 64.0)) * 64)
+            if (ph, pw) != (H, Wd):
+                n = self.engine.sn_run(self.engine.resize_bilinear(x, ph, pw), self.prompt_embeds, self.yoso_timestep, self.timesteps, self.ca, self.cb)
+                return self.engine.resize_bilinear(n, H, Wd, normalise=True)
+        if H % 64 or Wd % 64:
+            raise ValueError("height and width must be multiples of 64 (or set processing_resolution)")
         return self.engine.sn_run(x, self.prompt_embeds, self.yoso_timestep, self.timesteps, self.ca, self.cb)
 
     def __call__(self, image):
