@@ -791,6 +791,7 @@ int ug_tune_force(ug_ctx* x, int cfg, int split) {
   return 0;
 }
 int ug_tune_flash(int variant) { flash_set_variant(variant); return 0; }
+int ug_tune_ff(int variant) { ff_fused_set_variant(variant); return 0; }
 
 // GEMM / conv microbenchmark on device-resident pseudo-random data: average ms per launch over `iters`.
 int ug_bench_gemm(ug_ctx* x, int M, int N, int K, int conv, int T, int Hi, int Wi, int C0, int C1, int kt, int k,

@@ -103,6 +103,7 @@ struct FFusedP {
 };
 bool ff_fused_supported(int C);
 void launch_ff_fused(const FFusedP& p, hipStream_t s);
+void ff_fused_set_variant(int v);   // A/B aid (ug_tune_ff): 1 = GEGLU pipelined across chunks (default), 0 = round-2 kernel
 
 // ---------------------------------------------------------------------------------------
 // Normalisation (kernels/norm.hip)
