@@ -178,6 +178,47 @@ def cpu_baseline(threads, T=3, H=192, W=256, steps=2, stated=False):
             "extrapolated_clip_seconds": {k: round(v, 1) for k, v in full.items()}}
 
 
+def cpu_baseline_stablenormal(threads):
+    """BASELINE.md 4 for configs[3]: the CPU oracle's StableNormal predictor (torch-CPU fp32 restatement of the hub predictor - the real one is
+    un-vendored, so kind = "port") on ONE 576 x 576 image with the full YOSO + 10-step refinement schedule (~15 TFLOP: 15-30 s on the
+    host cores) - the same workload as the GPU line's batch-1 rate, nothing extrapolated."""
+    import torch
+    from oracle.stablenormal import AutoencoderKL, ControlNet, DinoConfig, DinoV2, SDUNet, SDUNetConfig, run_stablenormal
+    from oracle.vae import VAEConfig
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(0)
+    block = torch.empty(1 << 20).uniform_(-0.02, 0.02, generator=g)
+
+    def build(ctor):
+        with torch.device("meta"):
+            m = ctor()
+        m = m.to_empty(device="cpu")
+        with torch.no_grad():
+            for p_ in m.parameters():
+                flat, nb = p_.view(-1), block.numel()
+                full = flat.numel() // nb
+                if full:
+                    flat[:full * nb].view(full, nb).copy_(block)
+                flat[full * nb:].copy_(block[:flat.numel() - full * nb])
+        return m.eval()
+    t0 = time.time()
+    uc, vc, dc = SDUNetConfig(), VAEConfig(), DinoConfig()
+    mods = dict(vae=build(lambda: AutoencoderKL(vc)), unet_y=build(lambda: SDUNet(uc)), ctrl_y=build(lambda: ControlNet(uc)),
+                unet_r=build(lambda: SDUNet(uc)), ctrl_d=build(lambda: ControlNet(uc, dino_dim=dc.hidden_size)), dino=build(lambda: DinoV2(dc)))
+    t_init = time.time() - t0
+    H = W = 576
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    img = np.clip(np.stack([127.5 + 100 * np.sin(xx / 41.0 + c) * np.cos(yy / 29.0) for c in range(3)], -1), 0, 255).astype(np.uint8).astype(np.float32)[None] / 255.0
+    prompt = np.random.default_rng(1).standard_normal((77, uc.cross_attention_dim)).astype(np.float32) * 0.1
+    t0 = time.time()
+    with torch.no_grad():
+        run_stablenormal(mods["vae"], mods["unet_y"], mods["ctrl_y"], mods["unet_r"], mods["ctrl_d"], mods["dino"], img, prompt)
+    wall = time.time() - t0
+    return {"value": 1.0 / wall, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (torch-CPU fp32 restatement of the hub predictor; un-vendored) StableNormal on one 576x576 image, YOSO + 10 refinement steps: {wall:.1f} s wall on {threads} threads",
+            "sample_wall_s": round(wall, 2), "weight_init_s": round(t_init, 1)}
+
+
 def bench_stablenormal(a):
     """BASELINE configs[3]: StableNormal on 576x576 images (reference model/stablenormal.py:39 calls the predictor once per frame, so
     the headline is batch 1; the batched rate - the frames of a clip as one ug_sn_run call - is reported beside it).  One JSON line."""
@@ -221,9 +262,26 @@ def bench_stablenormal(a):
            "value_batch8": round(v8, 3), "value_clip25_384x512": round(v25, 3),
            "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS_F16, 4),
                         "traffic": None, "kernel": "gemm_kernel family (batch-1 image: M = 5184 / 1296 / 324 / 81 rows per level - launch- and weight-bandwidth-bound)",
+                        "algorithmic_bytes_per_launch": round(sum(v.get("bytes", 0) for v in gem.values()) / max(calls, 1)),
                         "launches": calls, "avg_launch_us": round(g_ms * 1000.0 / max(calls, 1), 2), "algorithmic_tflop": round(g_fl / 1e12, 3)},
-           "kernel_ms": {k: round(v["ms"], 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+           "kernel_ms_event_bracketed": {k: round(v["ms"], 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+           "parity": "unpinned: the predictor is a restatement of the published design, never run next to the hub code (DESIGN.md section 9)",
            "cpu_baseline": None}
+    try:   # HBM traffic of the same kernel family for this workload: tools/pmc_traffic.sh sn -> profiles/r03_pmc_traffic_gemm_sn.json, cited by hash
+        import hashlib
+        raw = open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_gemm_sn.json"), "rb").read()
+        pm = json.loads(raw)
+        res["roofline"]["traffic"] = round(pm["hbm_bytes_per_launch"])
+        res["roofline"]["traffic_source"] = {"file": "profiles/r03_pmc_traffic_gemm_sn.json", "sha256": hashlib.sha256(raw).hexdigest(), "script": "tools/pmc_traffic.sh sn",
+                                             "traffic_over_algorithmic": pm.get("traffic_over_algorithmic")}
+    except Exception:
+        pass
+    if not a.no_cpu_baseline:
+        try:
+            res["cpu_baseline"] = cpu_baseline_stablenormal(min(os.cpu_count() or 1, 32))
+        except Exception as e:
+            res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+    res["calibration"] = calibration_probe(eng)
     print(json.dumps(res), flush=True)
 
 
@@ -357,15 +415,17 @@ def main():
                                        "sub-pixel kernel (gemm_conv_up2x2) executes 4 taps - its apparent > 1 PFLOP/s rates in per-shape tables are not MFMA rates",
                                "algorithmic_bytes_per_launch": round(sum(v.get("bytes", 0) for v in gem.values()) / max(g_calls, 1))}
             # HBM traffic of the same kernel family: rocprofv3 PMC passes collected by the committed script tools/pmc_traffic.sh
-            # (FETCH_SIZE and WRITE_SIZE in separate passes, counters only) -> profiles/r02_pmc_traffic_gemm.json, which
+            # (FETCH_SIZE and WRITE_SIZE in separate passes, counters only) -> profiles/r03_pmc_traffic_gemm.json, which
             # also carries the algorithmic bytes of ITS OWN step mix; the file is cited by hash
             try:
                 import hashlib
-                pf = os.path.join(ROOT, "profiles", "r02_pmc_traffic_gemm.json")
+                pf = os.path.join(ROOT, "profiles", "r03_pmc_traffic_gemm.json")
+                if not os.path.exists(pf):
+                    pf = os.path.join(ROOT, "profiles", "r02_pmc_traffic_gemm.json")
                 raw = open(pf, "rb").read()
                 pm = json.loads(raw)
                 res["roofline"]["traffic"] = round(pm["hbm_bytes_per_launch"])
-                res["roofline"]["traffic_source"] = {"file": "profiles/r02_pmc_traffic_gemm.json", "sha256": hashlib.sha256(raw).hexdigest(),
+                res["roofline"]["traffic_source"] = {"file": "profiles/" + os.path.basename(pf), "sha256": hashlib.sha256(raw).hexdigest(),
                                                      "script": "tools/pmc_traffic.sh", "denoise_steps": pm.get("denoise_steps"),
                                                      "algorithmic_bytes_per_launch_same_mix": pm.get("algorithmic_bytes_per_launch"),
                                                      "traffic_over_algorithmic": pm.get("traffic_over_algorithmic"),

@@ -8,9 +8,10 @@ for M, C in [(76800, 320), (19200, 320), (8192, 320), (76800, 256), (76800, 128)
     fl = 2.0 * M * (8 * C) * C + 2.0 * M * C * (4 * C)
     eng.bench_ff(M, C, True)                     # cold run of the shape: discard
     eng.lib.ug_tune_ff(0); a8 = min(eng.bench_ff(M, C, True) for _ in range(2))      # round-2 kernel
-    eng.lib.ug_tune_ff(1); a = min(eng.bench_ff(M, C, True) for _ in range(2))       # GEGLU pipelined across chunks (default)
+    eng.lib.ug_tune_ff(1); a = min(eng.bench_ff(M, C, True) for _ in range(2))       # GEGLU pipelined across chunks
+    eng.lib.ug_tune_ff(2); ax = min(eng.bench_ff(M, C, True) for _ in range(2))      # cross-tile prefetch (default)
     b = eng.bench_ff(M, C, False)
-    print(f"M={M:6d} C={C:4d}: fused(pipelined GEGLU) {a:8.1f} us {fl / a / 1e6:7.0f} TF/s | fused(round 2) {a8:8.1f} us {fl / a8 / 1e6:7.0f} TF/s | "
+    print(f"M={M:6d} C={C:4d}: fused(cross-tile) {ax:8.1f} us {fl / ax / 1e6:7.0f} TF/s | fused(pipelined GEGLU) {a:8.1f} us {fl / a / 1e6:7.0f} TF/s | fused(round 2) {a8:8.1f} us {fl / a8 / 1e6:7.0f} TF/s | "
           f"two launches {b:8.1f} us {fl / b / 1e6:7.0f} TF/s | x{b / a:.2f}", flush=True)
 
 if len(sys.argv) > 1 and sys.argv[1] == "ablate":
@@ -24,4 +25,4 @@ if len(sys.argv) > 1 and sys.argv[1] == "ablate":
         eng.lib.ug_tune_ff(100 + a)
         us = min(eng.bench_ff(M, C, True) for _ in range(3))
         print(f"ablate {a:2d} ({names[a]:40s}): {us:7.1f} us", flush=True)
-    eng.lib.ug_tune_ff(1)
+    eng.lib.ug_tune_ff(2)

@@ -25,7 +25,9 @@ if "FETCH_SIZE" in out and "WRITE_SIZE" in out and out["FETCH_SIZE"]["dispatch_r
     rd = out["FETCH_SIZE"]["sum"] * 1024 * 2 / nl         # counters are in KB; FETCH doubled (gfx950 note)
     wr = out["WRITE_SIZE"]["sum"] * 1024 / nl
     alg = ev.get("algorithmic_bytes_per_launch")
-    json.dump({"workload": f"tools/one_clip.py {ev.get('denoise_steps')} (25x384x512 clip, CLIP + VAE enc/dec + that many Euler steps), GEMM-family dispatches only",
+    sn = isinstance(ev.get("denoise_steps"), str)
+    json.dump({"workload": ("tools/one_image_sn.py (" + ev["denoise_steps"] + "), GEMM-family dispatches only") if sn else
+                           f"tools/one_clip.py {ev.get('denoise_steps')} (25x384x512 clip, CLIP + VAE enc/dec + that many Euler steps), GEMM-family dispatches only",
                "denoise_steps": ev.get("denoise_steps"), "dispatches": n, "hip_event_gemm_launches": ev.get("gemm_launches"),
                "FETCH_SIZE_sum_KB": out["FETCH_SIZE"]["sum"], "WRITE_SIZE_sum_KB": out["WRITE_SIZE"]["sum"],
                "counter_csv_sha256": {k: v["csv_sha256"] for k, v in out.items()},

@@ -50,7 +50,11 @@ __device__ __forceinline__ int ffswz(int row) { return (row >> 1) & 7; }   // 12
 
 // ABL (tools/bench_ff.py ablate): timing-only variants of the kernel with one ingredient removed - WRONG RESULTS, never launched by the engine.
 // 1 = no GEGLU arithmetic, 2 = no weight-packet loads after the first two, 4 = no MFMAs, 8 = no fragment reads, 16 = no per-packet barrier
-template <int KT, int ABL = 0>   // KT = C / 64 K tiles of the X operand (C = 64 * KT <= 320)
+// XT (round 3): the weight-packet ring runs CONTINUOUSLY across the tiles a workgroup walks (the packets do not depend on the tile), and the
+// next tile's X rows are fetched into Xs as soon as the last chunk's phase A is over - behind the two phase-B packets still to come and the
+// whole epilogue.  The ablation (tools/bench_ff.py ablate, profiles/r03_ff_ablation.txt) showed 29 % of this kernel in the per-tile skeleton:
+// every CU of the chip sits in its prologue (80 KB of X), then in its epilogue (80 KB of residual in, 80 KB out) at the same moment.
+template <int KT, int ABL = 0, bool XT = false>   // KT = C / 64 K tiles of the X operand (C = 64 * KT <= 320)
 __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
   constexpr int C = KT * 64;
   constexpr int NP = (C + 127) / 128;          // phase-B pieces: NPF full ones of 128 output columns + (C % 128 == 64) one of 64
@@ -114,17 +118,29 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
   // loads per wave of packet s (compile-time when s is)
   auto nload = [](int s) { return (TAIL && s == STEPS - 1) ? 1 : 2; };
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int m0 = tile * 128;
-    // ---- X tile: KT x 16 wave-instructions of 1 KiB, spread over the 8 waves
+  static_assert(!XT || (KT >= 2 && NP >= 2), "cross-tile prefetch needs two phase-B packets after the last phase A");
+  constexpr int NX = KT * 2;                    // X-tile loads per wave
+  // ---- X tile: KT x 16 wave-instructions of 1 KiB, spread over the 8 waves
+  auto issue_x = [&](int m0_) {
     for (int t = wave; t < KT * 16; t += 8) {
       const int kt = t >> 4, r = t & 15;
       const int lr = r * 8 + lrow;
       const unsigned vo = vox + (unsigned)((r * 8 * C + (pc ^ ffswz(lr)) * 8) * 2);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lptr_t)(Xs + kt * TILE + r * 8 * 64), 16, (int)vo, (m0 * C + kt * 64) * 2, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lptr_t)(Xs + kt * TILE + r * 8 * 64), 16, (int)vo, (m0_ * C + kt * 64) * 2, 0, 0);
     }
-    issue_packet(0, 0, 0);
-    issue_packet(0, 1, 1);
+  };
+  int slot = 0;                       // ring slot of the packet being consumed (XT: runs on across tiles)
+  if (XT && (int)blockIdx.x < ntiles) { issue_x(blockIdx.x * 128); issue_packet(0, 0, 0); issue_packet(0, 1, 1); }
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m0 = tile * 128;
+    const bool more = XT && tile + (int)gridDim.x < ntiles;      // this workgroup has another tile after this one
+    if (!XT) {
+      issue_x(m0);
+      issue_packet(0, 0, 0);
+      issue_packet(0, 1, 1);
+      slot = 0;
+    }
 
     if (p.ln_g) {
       // ---- pre-norm on the LDS tile: 4 threads per token row (2 chunks of 8 channels in each of the KT K tiles), exact two-pass
@@ -194,14 +210,19 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
         for (int pp = 0; pp < NP; ++pp) acc2[pp][i][jn] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
 
-    int slot = 0;                       // ring slot of the packet being consumed
     bool first = true;                  // the X tile's loads are still in flight before the very first packet
     for (int j = 0; j < nchunk; ++j) {
 #pragma unroll
       for (int s = 0; s < STEPS; ++s) {
         // packet (j, s) must have landed; the next packet (issued one step ago) may stay in flight
         const bool last = (j == nchunk - 1) && (s == STEPS - 1);
-        if (first || last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (XT && more && j == nchunk - 1 && s > KT && s <= KT + 2) {
+          // the next tile's X loads (NX per wave, issued at s == KT behind packet KT + 2) sit between this tile's last packets in the queue:
+          // packet s must have landed, the X loads and the packet behind them may stay in flight
+          if (s == KT + 1) { if (nload((KT + 2) % STEPS) == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NX + 1) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NX + 2) : "memory"); }
+          else { if (KT + 3 < STEPS && nload(KT + 3) == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NX + 1) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NX + 2) : "memory"); }
+        }
+        else if (first || (last && !more)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (nload((s + 1) % STEPS) == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         if (first) {   // steady state below assumes exactly one younger packet in flight: re-establish it
@@ -215,7 +236,9 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
           if (s2 >= STEPS) { s2 -= STEPS; ++j2; }
           int slot2 = slot + 2; if (slot2 >= 3) slot2 -= 3;
           if (j2 < nchunk) issue_packet(j2, s2, slot2);
+          else if (more) issue_packet(0, s2, slot2);            // XT: the stream runs on into the next tile's first packets
         }
+        if (XT && more && j == nchunk - 1 && s == KT) issue_x(m0 + (int)gridDim.x * 128);   // every wave is past its last read of Xs (this packet's barrier)
         const f16* Wt = ring + slot * TILE;
         if (++slot == 3) slot = 0;
         if (s < KT) {
@@ -328,9 +351,11 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
       }
     }
     // the next tile's X loads overwrite Xs / the ring: everybody must be past this tile's LDS reads, and the epilogue's
-    // loads / stores must not be counted against the next tile's packets
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    // loads / stores must not be counted against the next tile's packets (XT: the first packet of the next tile waits for everything)
+    if (!XT) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
   }
 }
 
@@ -645,8 +670,8 @@ __global__ __launch_bounds__(512, 2) void ff_fused_pipe_kernel(const FFusedP p) 
   }
 }
 
-static int g_ff_variant = 1;    // process default (ug_tune_ff, an A/B aid): 1 = GEGLU software-pipelined across chunks, 0 = the round-2 kernel
-void ff_fused_set_variant(int v) { g_ff_variant = v >= 100 ? v : (v ? 1 : 0); }
+static int g_ff_variant = 2;    // process default (ug_tune_ff, an A/B aid): 2 = cross-tile prefetch, 1 = GEGLU software-pipelined across chunks, 0 = the round-2 kernel
+void ff_fused_set_variant(int v) { g_ff_variant = v; }
 
 template <int KT>
 static void launch_ff_t(const FFusedP& p, hipStream_t s) {
@@ -668,6 +693,16 @@ static void launch_ff_t(const FFusedP& p, hipStream_t s) {
         case 31: go(ff_fused_kernel<5, 31>); break; case 18: go(ff_fused_kernel<5, 18>); break; case 10: go(ff_fused_kernel<5, 10>); break;
         default: go(ff_fused_kernel<5, 0>); break;
       }
+      return;
+    }
+  }
+  if (g_ff_variant == 2) {
+    if constexpr (KT >= 2 && (KT * 64 + 127) / 128 >= 2) {
+      static bool attrx[32] = {};
+      bool& atx = attrx[ug_dev_slot()];
+      if (!atx) { UG_CHECK(hipFuncSetAttribute((const void*)ff_fused_kernel<KT, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); atx = true; }
+      const int per_cu_x = std::max(1, std::min(2, (int)((160 * 1024) / lds)));
+      hipLaunchKernelGGL((ff_fused_kernel<KT, 0, true>), dim3(std::min(ntiles, per_cu_x * 256)), dim3(512), lds, s, p);
       return;
     }
   }
