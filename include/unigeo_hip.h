@@ -106,12 +106,17 @@ int ug_set_concurrency(ug_ctx* ctx, int lanes);
 /* Tuning / parity aids for the fused GEGLU feed-forward kernel of the narrow transformer blocks (kernels/ff_fused.hip; the reference's
  * FeedForward module inside the un-vendored UNet): ug_set_ff_fused(0) falls back to two GEMM launches; ug_op_ff evaluates
  * c0 * (GEGLU(X W1^T + b1) W2^T + b2) + c1 * R1 on [M, C] with either implementation (W1 [8C][C], b1 [8C], W2 [C][4C] in diffusers order). */
-int ug_set_ff_fused(ug_ctx* ctx, int on);   /* bit 0: fused kernel, bit 1: the block's LayerNorm inside it (default 3) */
+int ug_set_ff_fused(ug_ctx* ctx, int on);   /* bit 0: fused feed-forward kernel, bit 1: the block's LayerNorm inside it, bit 2: fused LayerNorm -> Q|K|V projection (measured slower, off); default 3 */
 /* The same block with its pre-norm (reference: BasicTransformerBlock.norm3 -> ff, TemporalBasicTransformerBlock.norm_in -> ff_in, inside
  * the un-vendored UNet): out = c0 * FF(LayerNorm(x') * gamma + beta) + c1 * x', x' = fp16(X + addvec[row / rows_per_vec]) (addvec NULL: x' = X).
  * mode 0: LayerNorm launch + two GEMMs, 1: LayerNorm launch + fused feed-forward, 2: all inside the fused kernel (product path at C <= 320). */
 int ug_op_ln_ff(ug_ctx* ctx, const float* X, int M, int C, const float* gamma, const float* beta, float eps, const float* addvec, int rows_per_vec,
                 const float* W1, const float* b1, const float* W2, const float* b2, float c0, float c1, int mode, float* out);
+/* LayerNorm -> linear as one kernel (the Q|K|V projections of the narrow transformer blocks; reference: BasicTransformerBlock.norm1 -> attn1.to_q/k/v
+ * and TemporalBasicTransformerBlock.norm1 -> attn1 inside the un-vendored UNet).  out [M, N] = LN(X [M, C]) . W [N, C]^T + bias; fused = 0 runs the
+ * LayerNorm launch + GEMM it replaces; iters > 0 also times the call (us_out). */
+int ug_op_ln_linear(ug_ctx* ctx, const float* X, int M, int C, const float* gamma, const float* beta, float eps, const float* W, int N, const float* bias,
+                    int fused, int iters, float* out, float* us_out);
 int ug_bench_flash(ug_ctx* ctx, int B, int H, int S, int variant, int iters, float* us_out);   /* flash-attention A/B on device-resident random data */
 int ug_bench_ff(ug_ctx* ctx, int M, int C, int fused, int iters, float* us_out);
 int ug_op_ff(ug_ctx* ctx, const float* X, int M, int C, const float* W1, const float* b1, const float* W2, const float* b2, const float* R1,

@@ -443,6 +443,25 @@ def test_ff_fused_with_in_kernel_layernorm(engine, M, C, rpv):
     assert_close(got, two, 1.5e-3, f"in-kernel LayerNorm vs three launches {M}x{C}")
 
 
+@pytest.mark.parametrize("M,C,N,bias", [(300, 64, 192, True), (1000, 128, 384, False), (5000, 320, 960, False), (4100, 320, 320, True), (77, 256, 768, False),
+                                        (33000, 320, 960, False)])
+def test_ln_linear_fused(engine, M, C, N, bias):
+    """LayerNorm -> projection as one kernel (ln_linear_kernel: the Q|K|V projections of the narrow blocks; N = 960 has a 64-column last chunk, ragged M
+    exercises the dropped out-of-range buffer stores the counted waits rely on).  Against fp32 torch on the fp16-rounded operands and against the
+    LayerNorm launch + GEMM it replaces (same fp16 rounding of the normalised values, same MFMA chain per output)."""
+    rng = np.random.default_rng(M + C + N)
+    X = h16(rng.standard_normal((M, C)) * 2.0 + 0.5)
+    gamma, beta = h16(1.0 + 0.2 * rng.standard_normal(C)), h16(0.1 * rng.standard_normal(C))
+    W = h16(rng.standard_normal((N, C)) / np.sqrt(C))
+    b = h16(rng.standard_normal(N) * 0.1) if bias else None
+    got = engine.op_ln_linear(X, gamma, beta, W, b, fused=True)
+    two = engine.op_ln_linear(X, gamma, beta, W, b, fused=False)
+    ln = torch.nn.functional.layer_norm(t(X), (C,), t(gamma), t(beta), 1e-5).half().float()
+    ref = (ln @ t(W).T + (t(b) if bias else 0.0)).numpy()
+    assert_close(got, ref, 2e-3, f"fused LayerNorm + linear {M}x{N}x{C}")
+    assert_close(got, two, 1e-3, f"fused LayerNorm + linear vs two launches {M}x{N}x{C}")
+
+
 @pytest.mark.parametrize("C1", [0, 320])
 def test_conv_row_split_bitwise_full_size(engine, C1):
     """3x3 convolution onto 320 channels at the clip's level-0 size (25 x 48 x 64 = 76800 rows): launch_gemm runs the rows of the whole rounds

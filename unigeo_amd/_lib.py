@@ -18,7 +18,7 @@ EXPORTS = [
     "ug_unet_config_default", "ug_vae_config_default", "ug_clip_config_default",
     "ug_create", "ug_destroy", "ug_last_error", "ug_workspace_peak",
     "ug_load_tensor", "ug_bind_unet", "ug_bind_vae", "ug_bind_clip",
-    "ug_dc_set_inputs", "ug_dc_run", "ug_dc_run_windows", "ug_dc_get_outputs", "ug_dc_device_ptrs", "ug_dc_set_trace", "ug_set_vae_encode_fp32", "ug_set_concurrency", "ug_set_fp8_linears", "ug_op_linear_mx8", "ug_set_ff_fused", "ug_op_ff", "ug_op_ln_ff", "ug_bench_ff", "ug_bench_flash", "ug_tune_flash", "ug_tune_ff",
+    "ug_dc_set_inputs", "ug_dc_run", "ug_dc_run_windows", "ug_dc_get_outputs", "ug_dc_device_ptrs", "ug_dc_set_trace", "ug_set_vae_encode_fp32", "ug_set_concurrency", "ug_set_fp8_linears", "ug_op_linear_mx8", "ug_set_ff_fused", "ug_op_ff", "ug_op_ln_ff", "ug_op_ln_linear", "ug_bench_ff", "ug_bench_flash", "ug_tune_flash", "ug_tune_ff",
     "ug_eval_depth", "ug_eval_normal", "ug_clip_embed", "ug_vae_encode", "ug_vae_decode", "ug_unet_forward", "ug_normals_from_depth",
     "ug_op_linear", "ug_op_conv", "ug_op_groupnorm", "ug_op_layernorm", "ug_op_flash_attn",
     "ug_op_temporal_attn", "ug_op_attention_generic", "ug_op_euler_step",
@@ -91,6 +91,7 @@ def load_library():
         lib.ug_tune_ff.argtypes = [ip]
         lib.ug_op_ff.argtypes = [vp, vp, ip, ip, vp, vp, vp, vp, vp, C.c_float, C.c_float, ip, vp]
         lib.ug_op_ln_ff.argtypes = [vp, vp, ip, ip, vp, vp, C.c_float, vp, ip, vp, vp, vp, vp, C.c_float, C.c_float, ip, vp]
+        lib.ug_op_ln_linear.argtypes = [vp, vp, ip, ip, vp, vp, C.c_float, vp, ip, vp, ip, ip, vp, vp]
         lib.ug_op_linear_mx8.argtypes = [vp, vp, ip, ip, vp, ip, vp, ip, vp, vp, vp]
     except AttributeError:
         if not os.environ.get("UG_LIB_PATH"):      # only an explicitly selected OLDER build (tools/ab A/B runs) may lack these
@@ -310,9 +311,12 @@ class Engine:
         self._ck(self.lib.ug_bench_ff(self.ctx, int(M), int(C), int(bool(fused)), int(iters), _ptr(out)))
         return float(out[0])
 
-    def set_ff_fused(self, on=True, prenorm=True):
-        """Fused GEGLU feed-forward kernel of the narrow transformer blocks (on) and its LayerNorm inside the kernel (prenorm); A/B aid."""
-        self._ck(self.lib.ug_set_ff_fused(self.ctx, (1 if on else 0) | (2 if on and prenorm else 0)))
+    def set_ff_fused(self, on=True, prenorm=True, ln_qkv=None):
+        """Fused GEGLU feed-forward kernel of the narrow transformer blocks (on), its LayerNorm inside the kernel (prenorm) and the fused
+        LayerNorm -> Q|K|V projection kernel (ln_qkv; off unless asked for); A/B aid."""
+        if ln_qkv is None:
+            ln_qkv = False          # measured slower than LayerNorm launch + GEMM (tools/bench_lnqkv.py); opt-in
+        self._ck(self.lib.ug_set_ff_fused(self.ctx, (1 if on else 0) | (2 if on and prenorm else 0) | (4 if ln_qkv else 0)))
 
     def op_ln_ff(self, X, gamma, beta, W1, b1, W2, b2, addvec=None, rows_per_vec=1, eps=1e-5, c0=1.0, c1=1.0, mode=2):
         X = _f32(X); M, Cc = X.shape
@@ -321,6 +325,15 @@ class Engine:
         self._ck(self.lib.ug_op_ln_ff(self.ctx, _ptr(X), M, Cc, _ptr(_f32(gamma)), _ptr(_f32(beta)), float(eps), _ptr(av), int(rows_per_vec),
                                       _ptr(_f32(W1)), _ptr(_f32(b1)), _ptr(_f32(W2)), _ptr(_f32(b2)), float(c0), float(c1), int(mode), _ptr(out)))
         return out
+
+    def op_ln_linear(self, X, gamma, beta, W, bias=None, eps=1e-5, fused=True, iters=0):
+        """LayerNorm(X) @ W.T (+ bias); fused = the X-resident kernel, else LayerNorm launch + GEMM.  iters > 0: returns (out, microseconds per call)."""
+        X = _f32(X); M, Cc = X.shape; Wf = _f32(W); N = Wf.shape[0]
+        out = np.empty((M, N), np.float32); us = np.zeros(1, np.float32)
+        b = None if bias is None else _f32(bias)
+        self._ck(self.lib.ug_op_ln_linear(self.ctx, _ptr(X), M, Cc, _ptr(_f32(gamma)), _ptr(_f32(beta)), float(eps), _ptr(Wf), N, _ptr(b), int(bool(fused)), int(iters),
+                                          _ptr(out), _ptr(us)))
+        return (out, float(us[0])) if iters > 0 else out
 
     def op_ff(self, X, W1, b1, W2, b2, R1=None, c0=1.0, c1=1.0, fused=True):
         X = _f32(X); M, Cc = X.shape

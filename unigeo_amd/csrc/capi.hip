@@ -126,7 +126,7 @@ int ug_dc_run_windows(ug_ctx* x, int steps, int chunk, int with_normals, int win
 }
 int ug_set_ff_fused(ug_ctx* x, int on) {
   if (!x) return -1;
-  x->c.ff_fused = on & 3;   // bit 0: fused feed-forward kernel, bit 1: its pre-LayerNorm inside the kernel
+  x->c.ff_fused = on & 7;   // bit 0: fused feed-forward kernel, bit 1: its pre-LayerNorm inside the kernel, bit 2: fused LayerNorm -> Q|K|V projection
   return 0;
 }
 int ug_set_fp8_linears(ug_ctx* x, int on) {
@@ -568,6 +568,45 @@ int ug_op_ff(ug_ctx* x, const float* X, int M, int C, const float* W1, const flo
       gemm_apply_tune(g2, c.tune); launch_gemm(g2, 1, c.stream);
     }
     down16(c, dO, out, (long)M * C);
+  });
+}
+// LayerNorm(X) . W^T (+ bias) on [M, C] -> [M, N]: fused = 1 the X-resident kernel (kernels/ff_fused.hip: ln_linear_kernel), 0 = LayerNorm launch + GEMM
+int ug_op_ln_linear(ug_ctx* x, const float* X, int M, int C, const float* gamma, const float* beta, float eps, const float* W, int N, const float* bias,
+                    int fused, int iters, float* out, float* us_out) {
+  UG_TRY(x, {
+    Ctx& c = x->c; Scope sc(c);
+    f16* dX = up16(c, X, (long)M * C); f16* dW = up16(c, W, (long)N * C); f16* db = up16_opt(c, bias, N);
+    f16* dg = up16(c, gamma, C); f16* dbt = up16(c, beta, C);
+    f16* dO = c.ws.get<f16>((long)M * N); f16* t1 = c.ws.get<f16>((long)M * C);
+    auto run = [&]() {
+      if (fused) {
+        UG_REQUIRE(ln_linear_supported(C, N), "ln_linear: unsupported C / N");
+        LnLinP p; memset(&p, 0, sizeof(p));
+        p.X = dX; p.W = dW; p.bias = db; p.Out = dO; p.ldo = N; p.M = M; p.C = C; p.N = N; p.ln_g = dg; p.ln_b = dbt; p.ln_eps = eps;
+        launch_ln_linear(p, c.stream);
+      } else {
+        LayerNormP l; memset(&l, 0, sizeof(l));
+        l.X = dX; l.Y = t1; l.M = M; l.C = C; l.eps = eps; l.gamma = dg; l.beta = dbt; l.rows_per_vec = 1;
+        launch_layernorm(l, c.stream);
+        GemmP g1; memset(&g1, 0, sizeof(g1));
+        g1.A0 = t1; g1.C0 = C; g1.M = M; g1.N = N; g1.K = C; g1.W = dW; g1.ldw = C; g1.bias = db; g1.c0 = 1.f; g1.Out = dO; g1.ldo = N; g1.zero = c.zero; g1.nb_inner = 1;
+        g1.splitk = 1;
+        gemm_apply_tune(g1, c.tune); launch_gemm(g1, 1, c.stream);
+      }
+    };
+    run();
+    if (iters > 0 && us_out) {
+      run();
+      hipEvent_t e0, e1; UG_CHECK(hipEventCreate(&e0)); UG_CHECK(hipEventCreate(&e1));
+      UG_CHECK(hipEventRecord(e0, c.stream));
+      for (int i = 0; i < iters; ++i) run();
+      UG_CHECK(hipEventRecord(e1, c.stream));
+      UG_CHECK(hipEventSynchronize(e1));
+      float ms = 0.f; UG_CHECK(hipEventElapsedTime(&ms, e0, e1));
+      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+      *us_out = ms * 1000.f / iters;
+    }
+    down16(c, dO, out, (long)M * N);
   });
 }
 int ug_bench_flash(ug_ctx* x, int B, int H, int S, int variant, int iters, float* us_out) {

@@ -101,6 +101,11 @@ struct FFusedP {
   // with addvec the R1 residual is taken as fp16(R1 + addvec[...]) as well (R1 == X: the block's residual stream)
   const f16* ln_g; const f16* ln_b; float ln_eps; const f16* addvec; int rows_per_vec;
 };
+// LayerNorm -> linear for the narrow blocks (kernels/ff_fused.hip, ln_linear_kernel): Out[M, N] (row stride ldo) = LN(X)[M, C] . W^T + bias, W [N][C];
+// ln_g == nullptr skips the LayerNorm (a plain X-resident projection)
+struct LnLinP { const f16* X; const f16* W; const f16* bias; f16* Out; long ldo; int M, C, N; const f16* ln_g; const f16* ln_b; float ln_eps; };
+bool ln_linear_supported(int C, int N);
+void launch_ln_linear(const LnLinP& p, hipStream_t s);
 bool ff_fused_supported(int C);
 void launch_ff_fused(const FFusedP& p, hipStream_t s);
 void ff_fused_set_variant(int v);   // A/B aid (ug_tune_ff): 1 = GEGLU pipelined across chunks (default), 0 = round-2 kernel

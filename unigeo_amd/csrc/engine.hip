@@ -945,6 +945,25 @@ static void ff_pair(Ctx& c, const f16* a, long M, const Lin& f1, const Lin& f2, 
   }
 }
 
+// out[M, l.out] = LayerNorm(x) . W^T (+ bias): on the narrow level (C <= 320, long tensors) ONE kernel with the activation tile resident in LDS
+// (kernels/ff_fused.hip: ln_linear_kernel) - the Q | K | V projections of the spatial and temporal attention; otherwise the LayerNorm launch
+// (writing t1) followed by the GEMM.  c.ff_fused bit 2 switches the fusion (A/B, parity tests).
+static void ln_linear(Ctx& c, const f16* x, long M, const Norm& ln, f16* t1, const Lin& l, f16* out, const QAct* q) {
+  if ((c.ff_fused & 4) && !c.fp8_linears && ln.g && ln.b && M >= 32768 && ln_linear_supported(l.in, l.out) && (long)M * l.out < (1L << 30)) {
+    LnLinP p; memset(&p, 0, sizeof(p));
+    p.X = x; p.W = l.w; p.bias = l.b; p.Out = out; p.ldo = l.out; p.M = (int)M; p.C = l.in; p.N = l.out; p.ln_g = ln.g; p.ln_b = ln.b; p.ln_eps = ln.eps;
+    char nm[64];
+    if (c.prof_on && c.prof_shapes) snprintf(nm, sizeof(nm), "gemm_ln_linear:%ldx%dx%d", M, l.out, l.in); else snprintf(nm, sizeof(nm), "gemm_ln_linear");
+    ProfScope ps(c, nm, 2.0 * M * (double)l.out * l.in, 2.0 * ((double)M * l.in + (double)l.out * l.in + (double)M * l.out));
+    launch_ln_linear(p, c.stream);
+    return;
+  }
+  layernorm(c, x, M, ln, t1, nullptr, 1, nullptr, q);
+  Epi e;
+  if (q) { e.a8 = q->a8; e.sa8 = q->sa; e.ld_sa8 = q->ld; }
+  linear(c, t1, M, l, out, e);
+}
+
 // y = FF(LayerNorm(x')) combined with the residual stream x' = x (+ addvec row): on the narrow level the LayerNorm runs inside the fused
 // feed-forward kernel - neither LayerNorm(x') nor x' are materialised (e2.R1 must be the stream: xout when addvec is given, else x);
 // otherwise the LayerNorm launch (writing t1 and xout) followed by ff_pair.
@@ -992,9 +1011,8 @@ static f16* transformer_forward(Ctx& c, const Transformer& tr, const f16* x, int
   const QAct* qp = q8 ? &qa : nullptr;
   auto qepi = [&](Epi e) { if (q8) { e.a8 = qa.a8; e.sa8 = qa.sa; e.ld_sa8 = qa.ld; } return e; };
   // ---- spatial block
-  layernorm(c, h0, M, tr.ln1, t1, nullptr, 1, nullptr, qp);
   f16* qkv = c.ws.get<f16>(M * 3 * C);
-  linear(c, t1, M, tr.qkv1, qkv, qepi(Epi()));
+  ln_linear(c, h0, M, tr.ln1, t1, tr.qkv1, qkv, qp);
   f16* ao = c.ws.get<f16>(M * C);
   {
     FlashP p; p.Q = qkv; p.K = qkv + C; p.V = qkv + 2 * C; p.ldq = p.ldk = p.ldv = 3 * C; p.O = ao; p.ldo = C;
@@ -1015,8 +1033,7 @@ static f16* transformer_forward(Ctx& c, const Transformer& tr, const f16* x, int
   f16* xm = h0;   // h0 is dead
   f16* g1 = h1;   // h1 is dead
   { Epi e; e.R1 = xm; ln_ff(c, hs, M, tr.ln_in, tr.frame_emb, HW, xm, t1, tr.ffin1, tr.ffin2, ffm, g1, e, qp); }
-  layernorm(c, g1, M, tr.tln1, t1, nullptr, 1, nullptr, qp);
-  linear(c, t1, M, tr.tqkv, qkv, qepi(Epi()));
+  ln_linear(c, g1, M, tr.tln1, t1, tr.tqkv, qkv, qp);
   {
     TemporalAttnP p; p.Q = qkv; p.K = qkv + C; p.V = qkv + 2 * C; p.ld = 3 * C; p.O = ao; p.ldo = C;
     p.T = T; p.HW = HW; p.H = tr.heads; p.scale = 0.125f;

@@ -28,6 +28,7 @@
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 // same packed-fp32 GEGLU as the GEMM epilogue (kernels/gemm.hip): h * g * Phi(g), erfc by Abramowitz-Stegun 7.1.26
 __device__ __forceinline__ f32x2 ff_geglu2(f32x2 h, f32x2 g) {
@@ -668,6 +669,249 @@ __global__ __launch_bounds__(512, 2) void ff_fused_pipe_kernel(const FFusedP p) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// LayerNorm -> linear projection for the narrow (level-0, C = 320) transformer blocks (round 3): Out[M, N] = LN(X)[M, C] . W^T (+ bias),
+// the Q | K | V projections (N = 3C) of the spatial and temporal attention.  As LayerNorm launch + GEMM launch this is the worst-placed pair
+// of the level (profiles/r03_per_shape_hip_events_25step.txt: 76800x960x320 at 92 us = 512 TFLOP/s, + 16 us of LayerNorm): five K steps per
+// tile, so a tile's time is its prologue and its 64 KB of stores, and the 49 MB activation is streamed once by LayerNorm (read + write) and
+// again, once per 128-column tile, by the GEMM.  Here - the fused feed-forward kernel's phase A, kept: the X tile [128 x C] is staged once,
+// normalised in LDS, and ALL N output columns are produced from it in chunks of 128 (weight packets [128 x 64] through the same 3-slot ring);
+// the activation is read once, LayerNorm(x) is never written.  A chunk's outputs are stored AFTER the next packet's barrier and fetch have
+// been issued (the queue then holds, oldest first, the two packets in flight and this wave's four stores - counted, never drained).
+template <int KT>
+__global__ __launch_bounds__(512, 2) void ln_linear_kernel(const LnLinP p) {
+  constexpr int C = KT * 64;
+  constexpr int TILE = 128 * 64;
+  extern __shared__ __attribute__((aligned(16))) f16 smem[];
+  f16* Xs = smem;                              // [KT][128][64]
+  f16* ring = smem + KT * TILE;                // [4][128][64]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int sw = ffswz(l15);
+  const int pc = lane & 7, lrow = lane >> 3;
+  const int nfull = p.N / 128;                 // chunks of 128 output columns ...
+  const bool half = (p.N % 128) != 0;          // ... + one of 64
+  const int nchunk = nfull + (half ? 1 : 0);
+  const int ntiles = (p.M + 127) / 128;
+  const int Q = nchunk * KT;                   // packets per tile
+
+  constexpr unsigned SENT = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)SENT, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (int)((long)p.M * C * 2), 0x00020000);   // rows >= M read zeros
+  const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)p.Out, 0, (int)((long)p.M * p.ldo * 2), 0x00020000);
+  unsigned vo[2], voh, vox;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {   // LDS row lr holds weight row perm(lr): wave tile 64 columns, 16 contiguous output columns per lane
+    const int lr = (wave * 2 + u) * 8 + lrow;
+    const int part = lr >> 6, rem = lr & 63, jj = rem >> 4, i = rem & 15;
+    const int n = part * 64 + (i >> 2) * 16 + jj * 4 + (i & 3);
+    vo[u] = (unsigned)((n * C + (pc ^ ffswz(lr)) * 8) * 2);
+  }
+  {   // half chunk: 64 weight rows, wave tile 32 columns (8 contiguous output columns per lane)
+    const int lr = wave * 8 + lrow;
+    const int part = lr >> 5, rem = lr & 31, jj = rem >> 4, i = rem & 15;
+    const int n = part * 32 + (i >> 2) * 8 + jj * 4 + (i & 3);
+    voh = (unsigned)((n * C + (pc ^ ffswz(lr)) * 8) * 2);
+  }
+  vox = (unsigned)((lrow * C + 0) * 2);
+  auto is_half = [&](int j) { return half && j == nchunk - 1; };
+  auto issue_packet = [&](int q, int slot) {      // packet q = (chunk j, K tile s)
+    const int j = q / KT, s = q - j * KT;
+    f16* dst = ring + slot * TILE;
+    const int so = (j * 128 * C + s * 64) * 2;
+    if (!is_half(j)) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(dst + (wave * 2 + u) * 8 * 64), 16, (int)vo[u], so, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(dst + wave * 8 * 64), 16, (int)voh, so, 0, 0);
+    }
+  };
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m0 = tile * 128;
+    for (int t = wave; t < KT * 16; t += 8) {
+      const int kt = t >> 4, r = t & 15;
+      const int lr = r * 8 + lrow;
+      const unsigned vx = vox + (unsigned)((r * 8 * C + (pc ^ ffswz(lr)) * 8) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lptr_t)(Xs + kt * TILE + r * 8 * 64), 16, (int)vx, (m0 * C + kt * 64) * 2, 0, 0);
+    }
+    issue_packet(0, 0);
+    if (Q > 1) issue_packet(1, 1);
+    if (Q > 2) issue_packet(2, 2);
+
+    if (p.ln_g) {
+      // pre-norm on the LDS tile: the fused feed-forward kernel's code (4 threads per token row, exact two-pass statistics in fp32)
+      const int row = tid >> 2, q4 = tid & 3;
+      f16x8 ga[KT][2], be[KT][2];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          ga[kt][u] = *(const f16x8*)(p.ln_g + kt * 64 + q4 * 16 + u * 8);
+          be[kt][u] = *(const f16x8*)(p.ln_b + kt * 64 + q4 * 16 + u * 8);
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      f16* xr = Xs + row * 64;
+      const int cs[2] = {((q4 * 2) ^ ffswz(row)) * 8, ((q4 * 2 + 1) ^ ffswz(row)) * 8};
+      f16x8 hx[KT][2];
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          hx[kt][u] = *(const f16x8*)(xr + kt * TILE + cs[u]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sum += (float)hx[kt][u][e];
+        }
+      sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
+      const float mean = sum / C;
+      float var = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float d = (float)hx[kt][u][e] - mean; var += d * d; }
+      var += __shfl_xor(var, 1); var += __shfl_xor(var, 2);
+      const float rstd = rsqrtf(var / C + p.ln_eps);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          f16x8 y;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] = (f16)(((float)hx[kt][u][e] - mean) * rstd * (float)ga[kt][u][e] + (float)be[kt][u][e]);
+          *(f16x8*)(xr + kt * TILE + cs[u]) = y;
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jn = 0; jn < 4; ++jn) acc[i][jn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // store chunk jd's finished accumulators (+ bias) and clear them; returns the number of stores this wave issued
+    auto flush = [&](int jd) {
+      const bool hf = is_half(jd);
+      const int n0 = jd * 128 + (hf ? wn * 32 + g * 8 : wn * 64 + g * 16);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 32 + i * 16 + l15;
+#pragma unroll
+        for (int e0 = 0; e0 < 16; e0 += 8) {
+          if (hf && e0 >= 8) continue;
+          f16x8 h;
+          if (p.bias) {
+            const f16x8 b = *(const f16x8*)(p.bias + n0 + e0);
+#pragma unroll
+            for (int qq = 0; qq < 8; ++qq) h[qq] = (f16)(acc[i][(e0 + qq) >> 2][(e0 + qq) & 3] + (float)b[qq]);
+          } else {
+#pragma unroll
+            for (int qq = 0; qq < 8; ++qq) h[qq] = (f16)acc[i][(e0 + qq) >> 2][(e0 + qq) & 3];
+          }
+          // buffer store: rows >= M land past num_records and are dropped by the hardware, so every wave issues exactly the same number of
+          // stores - the counted waits below depend on it
+          const unsigned off = m < p.M ? (unsigned)(((long)m * p.ldo + n0 + e0) * 2) : 0xFFFFFFF0u;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, h), rO, (int)off, 0, 0);
+        }
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) acc[i][jn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    };
+
+    int slot = 0;
+    int pend = -1;                       // chunk whose accumulators are complete but not yet stored
+    int behind = 0, since = 99;          // stores of the last flush (2 or 4 per wave) and the iterations since it
+    auto nl_of = [&](int qq) { return qq < Q ? (is_half(qq / KT) ? 1 : 2) : 0; };
+    for (int q = 0; q < Q; ++q) {
+      const int j = q / KT, s = q - j * KT;
+      // packet q must have landed.  Behind it in the (in-order) queue: packets q + 1 and q + 2 (fetched three ahead through a 4-slot ring) and,
+      // for three iterations after a flush, that flush's stores - counted, not drained: a store gets ~4 packet times to be acknowledged
+      // before it stands in front of a packet this wave waits for
+      const int allow = (q == 0) ? 0 : nl_of(q + 1) + nl_of(q + 2) + (since <= 2 ? behind : 0);
+      switch (allow) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (q + 3 < Q) issue_packet(q + 3, (slot + 3) & 3);     // the slot of packet q - 1: every wave is past its reads (this barrier)
+      ++since;
+      if (pend >= 0) {
+        // the previous chunk's outputs: issued behind the fetch above so that the next waits can count them instead of draining
+        behind = is_half(pend) ? 2 : 4; since = 0;
+        flush(pend); pend = -1;
+      }
+      const f16* Wt = ring + slot * TILE;
+      slot = (slot + 1) & 3;
+      const bool hf = is_half(j);
+      const f16* Ab = Xs + s * TILE + (wm * 32 + l15) * 64;
+      const f16* Bb = Wt + ((hf ? wn * 32 : wn * 64) + l15) * 64;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int ch = ((kk * 4 + g) ^ sw) * 8;
+        f16x8 bf[4], af[2];
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn)
+          if (!hf || jn < 2) bf[jn] = *(const f16x8*)(Bb + jn * 16 * 64 + ch);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *(const f16x8*)(Ab + i * 16 * 64 + ch);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int jn = 0; jn < 4; ++jn)
+            if (!hf || jn < 2) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[jn], af[i], acc[i][jn], 0, 0, 0);
+      }
+      if (s == KT - 1) pend = j;
+    }
+    if (pend >= 0) flush(pend);
+    // the next tile's X loads overwrite Xs / the ring: everybody must be past this tile's LDS reads, and the stores drained
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
+bool ln_linear_supported(int C, int N) { return (C == 64 || C == 128 || C == 192 || C == 256 || C == 320) && N >= 128 && N % 64 == 0; }
+
+template <int KT>
+static void launch_lnlin_t(const LnLinP& p, hipStream_t s) {
+  const size_t lds = (size_t)(KT + 4) * 128 * 64 * sizeof(f16);
+  static bool attr[32] = {};
+  bool& at = attr[ug_dev_slot()];
+  if (!at) { UG_CHECK(hipFuncSetAttribute((const void*)ln_linear_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); at = true; }
+  const int ntiles = (p.M + 127) / 128;
+  const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / lds)));
+  hipLaunchKernelGGL(ln_linear_kernel<KT>, dim3(std::min(ntiles, per_cu * 256)), dim3(512), lds, s, p);
+}
+
+void launch_ln_linear(const LnLinP& p, hipStream_t s) {
+  UG_REQUIRE(ln_linear_supported(p.C, p.N) && p.M > 0 && p.ldo >= p.N && p.ldo % 8 == 0, "ln_linear: C a multiple of 64 up to 320, N a multiple of 64");
+  if (p.ln_g) UG_REQUIRE(p.ln_b != nullptr, "ln_linear: beta missing");
+  switch (p.C / 64) {
+    case 1: launch_lnlin_t<1>(p, s); break;
+    case 2: launch_lnlin_t<2>(p, s); break;
+    case 3: launch_lnlin_t<3>(p, s); break;
+    case 4: launch_lnlin_t<4>(p, s); break;
+    default: launch_lnlin_t<5>(p, s); break;
+  }
+  UG_CHECK(hipGetLastError());
 }
 
 static int g_ff_variant = 2;    // process default (ug_tune_ff, an A/B aid): 2 = cross-tile prefetch, 1 = GEGLU software-pipelined across chunks, 0 = the round-2 kernel

@@ -1410,6 +1410,15 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
         if (sp >= 2) { cfg = 3; split = sp; }
       }
     }
+    // Round 3 (tools/tune_level3.py, profiles/r03_tune_level3.txt): the long-K launches of the lowest level (M = 1200: 3x3 / temporal convs, the
+    // 5120 -> 1280 projection) stream 10 - 60 MB of weights from HBM through 36 - 72 K steps per workgroup; the producer / consumer tiles
+    // (dedicated fetch waves two K steps ahead in a 3-slot ring) hide that latency better than the symmetric 2-stage 128x128 tile:
+    // conv 1280@6x8 62 -> 56 us, conv 2560@6x8 101 -> 87, tconv 37 -> 32, 1200x1280x5120 37 -> 33.  Knob 2048 = off.
+    if (!(p.tune_knobs & 2048) && plain_epi && p.M > 1024 && p.N >= 1024 && p.N < 2048 && gemm_can_bufa(p, 64, true)) {
+      if (p.conv && nk >= 128) { cfg = 59; split = 4; }
+      else if (p.conv && nk >= 48) { cfg = 63; split = 3; }
+      else if (!p.conv && nk >= 64) { cfg = 59; split = 3; }
+    }
   } else if (!(p.tune_knobs & 512) && plain_epi && p.M <= 8192 && tiles128 <= 256 && p.N >= 128 && p.N < 2048 && (p.conv ? nk >= 32 : nk >= 16)) {
     // Under-filled launch (a 72x72 / 36x36 latent of ONE image: 40 - 250 tiles of 128x128 for 256 CUs): the cost model above prices a
     // round by its tile size only and keeps the 256x128 tile on 63 workgroups; what helps is workgroups - 128x128 (im2col) or 128x64
