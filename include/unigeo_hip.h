@@ -97,6 +97,11 @@ int ug_dc_get_outputs(ug_ctx* ctx, float* frames_out, float* depth_out, float* n
  * fp32 residual stream / GroupNorm / softmax, GEMMs on fp16 hi/lo activation pairs against the (fp16-valued) weights, which is
  * exact to fp32 rounding.  on = 0: fp16 storage with fp32 accumulation, like the decoder (faster, ~1e-3 off the fp32 result). */
 int ug_set_vae_encode_fp32(ug_ctx* ctx, int on);
+/* GroupNorm launch scheme of the UNet-sized tensors (A/B, parity tests): on = 1 one launch - a workgroup keeps its rows in registers while the
+ * per-frame statistics are handed over through write-through partials and a ticket (kernels/norm.hip: gn_fused); on = 0 (default) the three launches
+ * (statistics / finalise / apply).  Same arithmetic up to the order of the fp32 chunk sums.  Measured: the hand-off (a chain of ~8 uncached round
+ * trips) costs more than the second read of the tensor it saves - 45 vs 40 us at level 0, 22 vs 16 us on the smallest tensors. */
+int ug_set_gn_fused(ug_ctx* ctx, int on);
 /* Independent sub-graphs of one pipeline call in flight at a time (default 1 = strictly one kernel after another; 2 measured -0.6 % on the headline clip).  The reference's
  * pipeline encodes / decodes the clip in chunks of `decode_chunk_size` frames one after the other and computes the CLIP embeddings before
  * them (the calls inside pipeline(...) at model/depthcrafter.py:80-90); those chunks do not depend on each other, so the engine issues them on

@@ -125,6 +125,26 @@ def test_groupnorm(engine, C, G, HW, T, temporal):
     assert_close(got, F.silu(y).numpy(), TOL, f"groupnorm C={C} temporal={temporal}")
 
 
+def test_groupnorm_one_launch_scheme(engine):
+    """The one-launch GroupNorm (rows in registers across a per-frame ticket hand-off; off by default because it measured slower) stays correct:
+    per-frame and pooled statistics, two sources, against torch and against the three-launch scheme."""
+    rng = np.random.default_rng(17)
+    for (T, HW, C0, C1, temporal) in [(25, 768, 640, 0, False), (25, 192, 1280, 0, True), (3, 100, 64, 32, False), (25, 3072, 320, 0, True)]:
+        C = C0 + C1
+        x0 = rnd(rng, T, HW, C0) + 0.25
+        x1 = rnd(rng, T, HW, C1) * 2 if C1 else None
+        gm, bt = rnd(rng, C) + 1, rnd(rng, C)
+        base = engine.op_groupnorm(x0, 32 if C % 32 == 0 else 16, 1e-6, gm, bt, x1=x1, temporal=temporal, silu=True)
+        engine.set_gn_fused(True)
+        try:
+            got = engine.op_groupnorm(x0, 32 if C % 32 == 0 else 16, 1e-6, gm, bt, x1=x1, temporal=temporal, silu=True)
+            again = engine.op_groupnorm(x0, 32 if C % 32 == 0 else 16, 1e-6, gm, bt, x1=x1, temporal=temporal, silu=True)
+        finally:
+            engine.set_gn_fused(False)
+        assert np.array_equal(got, again), "one-launch GroupNorm is not reproducible"
+        assert_close(got, base, 1e-3, f"one-launch vs three-launch GroupNorm T{T} HW{HW} C{C} temporal={temporal}")
+
+
 def test_groupnorm_concat_groups_straddle_sources(engine):
     rng = np.random.default_rng(3)
     C0, C1, G, HW, T = 1280, 640, 32, 48, 2        # 60 channels per group: group 21 straddles x0|x1

@@ -18,7 +18,7 @@ EXPORTS = [
     "ug_unet_config_default", "ug_vae_config_default", "ug_clip_config_default",
     "ug_create", "ug_destroy", "ug_last_error", "ug_workspace_peak",
     "ug_load_tensor", "ug_bind_unet", "ug_bind_vae", "ug_bind_clip",
-    "ug_dc_set_inputs", "ug_dc_run", "ug_dc_run_windows", "ug_dc_get_outputs", "ug_dc_device_ptrs", "ug_dc_set_trace", "ug_set_vae_encode_fp32", "ug_set_concurrency", "ug_set_fp8_linears", "ug_op_linear_mx8", "ug_set_ff_fused", "ug_op_ff", "ug_op_ln_ff", "ug_op_ln_linear", "ug_bench_ff", "ug_bench_flash", "ug_tune_flash", "ug_tune_ff",
+    "ug_dc_set_inputs", "ug_dc_run", "ug_dc_run_windows", "ug_dc_get_outputs", "ug_dc_device_ptrs", "ug_dc_set_trace", "ug_set_vae_encode_fp32", "ug_set_gn_fused", "ug_set_concurrency", "ug_set_fp8_linears", "ug_op_linear_mx8", "ug_set_ff_fused", "ug_op_ff", "ug_op_ln_ff", "ug_op_ln_linear", "ug_bench_ff", "ug_bench_flash", "ug_tune_flash", "ug_tune_ff",
     "ug_eval_depth", "ug_eval_normal", "ug_clip_embed", "ug_vae_encode", "ug_vae_decode", "ug_unet_forward", "ug_normals_from_depth",
     "ug_op_linear", "ug_op_conv", "ug_op_groupnorm", "ug_op_layernorm", "ug_op_flash_attn",
     "ug_op_temporal_attn", "ug_op_attention_generic", "ug_op_euler_step",
@@ -84,6 +84,7 @@ def load_library():
     try:
         lib.ug_set_fp8_linears.argtypes = [vp, ip]
         lib.ug_set_concurrency.argtypes = [vp, ip]
+        lib.ug_set_gn_fused.argtypes = [vp, ip]
         lib.ug_set_ff_fused.argtypes = [vp, ip]
         lib.ug_bench_ff.argtypes = [vp, ip, ip, ip, ip, vp]
         lib.ug_bench_flash.argtypes = [vp, ip, ip, ip, ip, ip, vp]
@@ -296,6 +297,10 @@ class Engine:
     def set_concurrency(self, lanes=2):
         """Independent chunks (VAE encode / decode chunks, CLIP tower) in flight on separate HIP streams; 1 = serial.  Bit-identical outputs."""
         self._ck(self.lib.ug_set_concurrency(self.ctx, int(lanes)))
+
+    def set_gn_fused(self, on=True):
+        """One-launch GroupNorm (rows kept in registers across the statistics hand-off) for the UNet-sized tensors; False = three launches."""
+        self._ck(self.lib.ug_set_gn_fused(self.ctx, int(bool(on))))
 
     def set_vae_encode_fp32(self, on=True):
         """True (default) = the reference's float32 VAE encoder (force_upcast); False = fp16 storage like the decoder."""

@@ -139,6 +139,11 @@ int ug_set_concurrency(ug_ctx* x, int lanes) {
   x->c.concurrency = std::max(1, std::min(lanes, 8));
   return 0;
 }
+int ug_set_gn_fused(ug_ctx* x, int on) {
+  if (!x) return -1;
+  x->c.gn_fused_on = on ? 1 : 0;
+  return 0;
+}
 int ug_set_vae_encode_fp32(ug_ctx* x, int on) {
   if (!x) return -1;
   x->c.vae_encode_fp32 = on ? 1 : 0;
@@ -742,8 +747,10 @@ int ug_op_groupnorm(ug_ctx* x, const float* x0, int C0, const float* x1, int C1,
     p.gamma = up16(c, gamma, C); p.beta = up16(c, beta, C);
     f16* y = c.ws.get<f16>(M * C); p.Y = y;
     p.ws = c.ws.get<float>((long)groupnorm_ws_floats(T, HW, C, G));
+    gn_attach(c, p);
     launch_groupnorm(p, c.stream);
     down16(c, y, out, M * C);
+    gn_check(c);
   });
 }
 
@@ -759,6 +766,7 @@ int ug_bench_groupnorm(ug_ctx* x, int C0, int C1, int T, int HW, int temporal, i
     p.X0 = a0; p.X1 = a1; p.C0 = C0; p.C1 = C1; p.T = T; p.HW = HW; p.G = 32; p.eps = 1e-5f; p.temporal = temporal; p.silu = 1;
     p.gamma = gm; p.beta = bt; p.Y = c.ws.get<f16>(M * C); p.mode = mode;
     p.ws = c.ws.get<float>((long)groupnorm_ws_floats(T, HW, C, 32));
+    auto launch_groupnorm = [&](GroupNormP& q, hipStream_t st) { gn_attach(c, q); if (mode == 1 || mode == 2) q.sync = nullptr; ::launch_groupnorm(q, st); };
     for (int i = 0; i < 3; ++i) launch_groupnorm(p, c.stream);
     hipEvent_t e0, e1; UG_CHECK(hipEventCreate(&e0)); UG_CHECK(hipEventCreate(&e1));
     UG_CHECK(hipEventRecord(e0, c.stream));

@@ -121,8 +121,11 @@ struct GroupNormP {
   const f16* gamma; const f16* beta;
   f16* Y;                 // [T*HW, C0+C1]
   float* ws;              // >= T * G * 2 * nchunk floats (+ T*G*2 for mean/rstd)
-  int mode;               // 0 = automatic; 1 / 2 force a launch scheme (launch_groupnorm)
+  int mode;               // 0 = automatic; 1 / 2 / 3 force a launch scheme (launch_groupnorm: three launches / one workgroup per group / one launch, rows in registers)
+  void* sync; unsigned tag;   // one-launch scheme: a zero-initialised GnSync block owned by the caller's context (per stream) and a tag unique to this launch;
+                              // sync == nullptr keeps the other schemes
 };
+size_t groupnorm_sync_bytes();
 void launch_groupnorm(const GroupNormP& p, hipStream_t s);
 size_t groupnorm_ws_floats(int T, int HW, int C, int G);
 

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <exception>
 #include <sstream>
 
 namespace ug {
@@ -39,6 +40,7 @@ struct RunGuard {
   ~RunGuard() {
     (void)hipStreamSynchronize(c.stream);
     for (auto& l : c.lanes) (void)hipStreamSynchronize(l.stream);
+    if (std::uncaught_exceptions() > 0 && c.gn_sync) (void)hipMemset(c.gn_sync, 0, groupnorm_sync_bytes() * 9);   // a call that died mid-way may leave tickets half counted
     c.ws.release(mk);
     c.unet.tproj = nullptr; c.unet.tproj_steps = 0;
     auto forget = [](Transformer& t) { t.frame_emb = nullptr; t.frame_emb_T = 0; t.cross_sp = nullptr; t.cross_tm = nullptr; };
@@ -123,17 +125,18 @@ static void run_lanes(Ctx& c, int ntask, Kind kind, Body body) {
         any = true;
         c.stream = c.lanes[l].stream;
         c.ws.view(base + (size_t)l * slice, slice);
+        c.cur_lane = l + 1;
         body(plan[l][k]);
       }
       if (!any) break;
     }
   } catch (...) {
-    c.stream = main_stream; c.ws = main_ws;
+    c.stream = main_stream; c.ws = main_ws; c.cur_lane = 0;
     for (int l = 0; l < nl; ++l) (void)hipStreamSynchronize(c.lanes[l].stream);
     c.ws.release(mk);
     throw;
   }
-  c.stream = main_stream; c.ws = main_ws;
+  c.stream = main_stream; c.ws = main_ws; c.cur_lane = 0;
   for (int l = 0; l < nl; ++l) {
     UG_CHECK(hipEventRecord(c.lanes[l].done, c.lanes[l].stream));
     UG_CHECK(hipStreamWaitEvent(main_stream, c.lanes[l].done, 0));
@@ -222,6 +225,30 @@ static void run_gemm(Ctx& c, GemmP p, int batch, const char* tag, float alg = 1.
     launch_gemm(p, batch, c.stream);
   }
   c.ws.release(mk);
+}
+
+static constexpr int kGnSyncSlots = 9;      // main stream + up to 8 lanes
+void gn_attach(Ctx& c, GroupNormP& p) {
+  if (!c.gn_fused_on) { p.sync = nullptr; return; }
+  if (!c.gn_sync) {
+    c.gn_sync = (char*)c.persist.alloc(groupnorm_sync_bytes() * kGnSyncSlots);
+    UG_CHECK(hipMemsetAsync(c.gn_sync, 0, groupnorm_sync_bytes() * kGnSyncSlots, c.stream));
+  }
+  p.sync = c.gn_sync + (size_t)std::min(c.cur_lane, kGnSyncSlots - 1) * groupnorm_sync_bytes();
+  p.tag = ++c.gn_tag;
+  if (p.tag == 0) p.tag = ++c.gn_tag;       // 0 is what a fresh block holds
+}
+void gn_check(Ctx& c) {
+  if (!c.gn_sync) return;
+  std::vector<unsigned> h(groupnorm_sync_bytes() * kGnSyncSlots / 4);
+  UG_CHECK(hipMemcpy(h.data(), c.gn_sync, h.size() * 4, hipMemcpyDeviceToHost));
+  const size_t per = groupnorm_sync_bytes() / 4;
+  bool bad = false;
+  for (int i = 0; i < kGnSyncSlots; ++i) bad |= h[i * per + 258] != 0;      // GnSync::err
+  if (bad) {
+    UG_CHECK(hipMemset(c.gn_sync, 0, groupnorm_sync_bytes() * kGnSyncSlots));
+    throw std::runtime_error("GroupNorm hand-off timed out (one-launch scheme): results of this call are invalid; ug_set_gn_fused(ctx, 0) selects the three-launch scheme");
+  }
 }
 
 void* pinned(Ctx& c, int slot, size_t bytes) {
@@ -326,6 +353,7 @@ static void groupnorm(Ctx& c, const f16* x0, int C0, const f16* x1, int C1, int 
   p.temporal = temporal; p.silu = silu; p.gamma = n.g; p.beta = n.b; p.Y = y;
   const size_t mk = c.ws.mark();
   p.ws = c.ws.get<float>((long)groupnorm_ws_floats(T, HW, n.c, G));
+  gn_attach(c, p);
   {
     char nm[96];
     if (c.prof_on && c.prof_shapes) snprintf(nm, sizeof(nm), "groupnorm:T%dxHW%dxC%d%s", T, HW, n.c, temporal ? "t" : "");
@@ -1618,6 +1646,7 @@ void dc_run(Ctx& c, int steps, int chunk, int with_normals, int window, int over
     launch_normals(c.d_depth, c.d_K, c.d_normals, T, H, W, c.stream);
   }
   UG_CHECK(hipStreamSynchronize(c.stream));
+  gn_check(c);
 }
 
 void dc_get_outputs(Ctx& c, float* frames, float* depth, float* normals) {
