@@ -1379,6 +1379,18 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
   // in-situ exception (tools/insitu_cfg_sweep.py): the level-0 down-projection (M = 76800, N = 320, K = 1280) re-reads its 197 MB
   // A operand once per 64-column tile; the 256x128 3-stage tile needs 3 instead of 5 passes (122 vs 131 us)
   if (!p.conv && !geglu && p.M >= 50000 && p.N > 256 && p.N <= 384 && p.K >= 1024) cfg = 4;
+  // Round 3: in-situ exceptions from a re-run of tools/insitu_cfg_sweep.py with the full config set (profiles/r03_gemm_insitu_cfg_sweep.txt: every GEMM of
+  // the clip forced to one tile at a time, operands wherever the producing kernel left them).  The cost model above is within 0 - 3 % of the in-situ
+  // best on most shapes; these classes were 4 - 19 % off.  Knob 4096 = off (tools/ab_clip.py insitu).
+  if (!(p.tune_knobs & 4096) && batch == 1) {
+    const bool bufa = gemm_can_bufa(p, 64, true);
+    if (!p.conv && geglu && p.M >= 4096 && p.N >= 4096 && p.K >= 512) cfg = bufa ? 35 : 15;              // 19200x5120x640: 129 vs 137 us; 4800x10240x1280: 113 vs 120
+    else if (!p.conv && geglu && p.K <= 384 && p.M < 32768 && p.M >= 4096) cfg = 64;                         // feed-forward tail rows 11264x2560x320: 34.6 vs 41.2
+    else if (!p.conv && !geglu && cfg == 63 && p.K >= 2048 && p.N <= 1280) cfg = 64;                          // 19200x640x2560: 74 vs 79; 4800x1280x5120: 66 vs 69
+    else if (!p.conv && !geglu && p.M >= 50000 && p.K <= 384 && p.N >= 640 && p.N < 2048 && bufa) cfg = 59;  // 76800x960x320 (Q|K|V): 77 vs 85
+    else if (!p.conv && !geglu && p.N <= 384 && p.K >= 1024 && p.M > 2048 && p.M <= 16384) cfg = 3;          // tail rows 11264x320x1280: 23.8 vs 28.0
+    else if (p.conv && p.kt > 1 && p.N <= 320 && p.M >= 50000) cfg = 14;                                      // temporal conv 76800x320x960: 80 vs 90
+  }
   int split = 1;
   const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * batch;
   const int nk = cdiv(p.K, 64);
