@@ -24,7 +24,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "mid":      # the 100-250-tile shapes of
              ("lin 1296x640x2560", dict(M=1296, N=640, K=2560)), ("lin 324x1280x5120", dict(M=324, N=1280, K=5120))]
 for name, kw in probs:
     row = []
-    for cfg in (0, 1, 3, 12):
+    for cfg in ((0, 1, 3, 12) if "ws" not in sys.argv else (0, 3, 19, 59, 63)):      # "ws": include the producer / consumer tiles (round 3)
         for sp in (1, 2, 4, 8, 12, 16, 24, 32):
             best = 1e9
             for r in range(2):

@@ -1422,6 +1422,19 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
         if (sp >= 2) { cfg = 3; split = sp; }
       }
     }
+    // Round 3 (tools/tune_splitk_small.py ... ws, profiles/r03_tune_sn_small.txt; knob 8192 = off): the batch-1 StableNormal shapes again, now with the
+    // producer / consumer tiles in the sweep.  im2col with >= 2 row tiles: the 192x128 producer / consumer tile, K sliced until ~160 workgroups are in
+    // flight (conv1280@18x18 37 -> 33 us, conv640@36x36 36 -> 32); a single row tile (M <= 128): 3-stage 128x64 tiles, ~240 workgroups
+    // (conv1280@9x9 27 -> 24); dense mid-length K loops with few tiles: two slices (1296x640x2560 23 -> 18).
+    if (!(p.tune_knobs & 8192) && plain_epi && p.N >= 128) {
+      const long t192 = (long)cdiv(p.M, 192) * cdiv(p.N, 128), t64b = (long)cdiv(p.M, 128) * cdiv(p.N, 64);
+      if (p.conv && p.M > 128 && t192 <= 128 && nk >= 16 && gemm_can_bufa(p, 64, true)) {
+        cfg = 63; split = (int)std::max<long>(1, std::min<long>(std::min<long>(160 / t192, nk / 8), 8));
+      } else if (p.conv && p.M <= 128 && nk >= 64) {
+        const int sp = (int)std::min<long>(std::min<long>(240 / t64b, nk / 7), 24);
+        if (sp >= 2) { cfg = 3; split = sp; }
+      } else if (!p.conv && split == 1 && nk >= 32 && t64b <= 128 && t64b > 64) split = 2;
+    }
     // Round 3 (tools/tune_level3.py, profiles/r03_tune_level3.txt): the long-K launches of the lowest level (M = 1200: 3x3 / temporal convs, the
     // 5120 -> 1280 projection) stream 10 - 60 MB of weights from HBM through 36 - 72 K steps per workgroup; the producer / consumer tiles
     // (dedicated fetch waves two K steps ahead in a 3-slot ring) hide that latency better than the symmetric 2-stage 128x128 tile:
@@ -1435,7 +1448,10 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
     // Under-filled launch (a 72x72 / 36x36 latent of ONE image: 40 - 250 tiles of 128x128 for 256 CUs): the cost model above prices a
     // round by its tile size only and keeps the 256x128 tile on 63 workgroups; what helps is workgroups - 128x128 (im2col) or 128x64
     // (dense) tiles, K sliced until ~512 are in flight (knob 512 = off; tools/ab_sn.py)
-    if (p.conv) {
+    const long t192u = (long)cdiv(p.M, 192) * cdiv(p.N, 128);
+    if (p.conv && !(p.tune_knobs & 8192) && t192u <= 128 && gemm_can_bufa(p, 64, true)) {
+      cfg = 63; split = (int)std::max<long>(1, std::min<long>(std::min<long>(160 / t192u, nk / 8), 8));     // conv320@72x72 36 -> 32 us (round 3)
+    } else if (p.conv) {
       int sp = (int)std::min<long>(std::min<long>(512 / tiles128, nk / 8), 8);
       while (sp >= 2 && (512 / sp) < tiles128) --sp;
       cfg = 0; split = std::max(1, sp);
@@ -1444,9 +1460,12 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
       cfg = 3;
       const int sp = (int)std::min<long>(std::min<long>(512 / t64, nk / 8), 8);
       split = std::max(1, sp);
+      if (!(p.tune_knobs & 8192) && t64 > 128) split = 1;     // round 3: with > 128 tiles the split costs more than it fills (5184x320x1280: 14.7 vs 22.0 us)
     }
   } else if (!geglu && !p.conv && p.M <= 512 && p.N >= 2048) {
     cfg = 3;   // wide projection of a few rows: many small tiles beat a handful of large ones (324x3840x1280: 14.4 vs 19.3 us)
+  } else if (!(p.tune_knobs & 8192) && !geglu && !p.conv && batch == 1 && p.M <= 8192 && p.K <= 384 && p.N <= 384) {
+    cfg = 3;   // round 3: short, narrow projections of one image (5184x320x320: 7.3 vs 9.6 us)
   }
   // (a former rule - four K slices of the 128x128 tile for the 12x16 level's concatenated 2560-channel convs, 880 TFLOP/s - is gone:
   // the 192-row tile fills the chip there without split-K, 236 vs 324 us = 1200 TFLOP/s)
