@@ -11,6 +11,7 @@ from unigeo_amd.model.depthcrafter import DepthCrafter
 
 cfgs = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 14, 15, 19]
 knobs = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+force_split = int(sys.argv[3]) if len(sys.argv) > 3 else 1      # round 3: the same sweep with every plain-epilogue GEMM sliced along K (in-situ split-K study)
 steps = 2
 T, H, W = 25, 384, 512
 pipe = DepthCrafterPipelineHIP.from_random(seed=42, workspace_bytes=40 << 30)
@@ -23,7 +24,7 @@ eng.run(1, 8)
 res = {}
 for c in [-1] + cfgs:
     eng.tune_force(-100 - knobs, 0)
-    eng.tune_force(c, 1 if c >= 0 else -1)
+    eng.tune_force(c, force_split if c >= 0 else -1)
     eng.run(1, 8)
     eng.profile_begin(shapes=True)
     eng.run(steps, 8)
