@@ -190,3 +190,21 @@ def test_processing_resolution_knob(tiny):
         pred.processing_resolution = 0
     with pytest.raises(ValueError):
         pred.predict_batch(rng.uniform(0, 1, (1, 100, 150, 3)).astype(np.float32))
+
+
+def test_guidance_branch_on_a_second_stream_is_bit_identical(tiny):
+    """ug_set_concurrency(2): the DINOv2 tower + DINO ControlNet are issued on a second HIP stream beside the YOSO estimate and joined before the
+    refinement loop (the first call of a shape runs in order and measures the branch's arena need).  Same kernels, same launch parameters."""
+    pred = tiny["pred"]
+    rng = np.random.default_rng(21)
+    img = rng.uniform(0, 1, (2, 64, 128, 3)).astype(np.float32)
+    pred.engine.set_concurrency(1)
+    base = pred.predict_batch(img)
+    pred.engine.set_concurrency(2)
+    try:
+        first = pred.predict_batch(img)        # measures (in order)
+        second = pred.predict_batch(img)       # overlapped
+        third = pred.predict_batch(img)
+    finally:
+        pred.engine.set_concurrency(2)
+    assert np.array_equal(first, base) and np.array_equal(second, base) and np.array_equal(third, base)

@@ -74,6 +74,9 @@ class StableNormalPredictorHIP:
         # normals are resized back to the input size and re-normalised.  UNPINNED like the rest of the predictor.
         self.processing_resolution = int(processing_resolution)
         self.prediction_type = prediction_type
+        # the DINO tower + DINO ControlNet run on a second HIP stream beside the YOSO estimate (one image's kernels fill a fraction of the chip);
+        # bit-identical to the in-order schedule (tests/test_stablenormal_gpu.py)
+        engine.set_concurrency(2)
         self.prompt_embeds = np.ascontiguousarray(prompt_embeds, dtype=np.float32)
         if self.prompt_embeds.shape != (77, cfgs[0].cross_attention_dim):
             raise ValueError(f"prompt_embeds must be [77, {cfgs[0].cross_attention_dim}]")
