@@ -204,6 +204,7 @@ int ug_op_layernorm(ug_ctx* ctx, const float* x, int M, int C, float eps, const 
 int ug_op_flash_attn(ug_ctx* ctx, const float* qkv /*[B*S,3*H*64]*/, int B, int H, int S, float* out /*[B*S,H*64]*/);
 int ug_op_temporal_attn(ug_ctx* ctx, const float* qkv /*[T*HW,3*H*64]*/, int T, int HW, int H, float* out);
 int ug_op_attention_generic(ug_ctx* ctx, const float* qkv /*[B*S,3*H*d]*/, int B, int S, int H, int d, float* out);
+int ug_op_flash_attn_dh(ug_ctx* ctx, const float* qkv /*[B*S,3*H*d]*/, int B, int S, int H, int d, float* out);   /* fused self-attention, head dim d in {32,48,80,96,112,128}: the CLIP tower's 16 x 80 heads */
 int ug_op_euler_step(ug_ctx* ctx, const float* v, float* latents_inout, long n, float sigma, float sigma_next);
 
 /* Tuning aids (not on the product path): GEMM / implicit-conv microbenchmark on device-resident random data,

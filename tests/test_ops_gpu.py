@@ -211,6 +211,17 @@ def test_generic_attention(engine, B, S, H, d):
     assert_close(engine.op_attention_generic(qkv, B, S, H, d), attn_ref(qkv, B, S, H, d), TOL, f"generic attn d={d}")
 
 
+@pytest.mark.parametrize("B,S,H,d", [(2, 257, 2, 80), (3, 50, 1, 80), (1, 64, 2, 128), (2, 130, 3, 32), (1, 257, 16, 80), (2, 77, 2, 96)])
+def test_flash_attention_other_head_dims(engine, B, S, H, d):
+    """Fused self-attention for head dims other than 64 (flash_attn_dh_kernel; the CLIP ViT-H/14 tower: 16 heads of 80, S = 257): ragged last
+    tile, padded d tile, against the fp32 reference and the four-launch path it replaces."""
+    rng = np.random.default_rng(S + d)
+    qkv = rnd(rng, B * S, 3 * H * d)
+    got = engine.op_flash_attn_dh(qkv, B, S, H, d)
+    assert_close(got, attn_ref(qkv, B, S, H, d), TOL, f"fused attention d={d} S={S}")
+    assert_close(got, engine.op_attention_generic(qkv, B, S, H, d), TOL, f"fused vs four-launch attention d={d} S={S}")
+
+
 def test_euler_step(engine):
     import sys, os
     from oracle.scheduler import EulerKarrasVPred

@@ -21,7 +21,7 @@ EXPORTS = [
     "ug_dc_set_inputs", "ug_dc_run", "ug_dc_run_windows", "ug_dc_get_outputs", "ug_dc_device_ptrs", "ug_dc_set_trace", "ug_set_vae_encode_fp32", "ug_set_gn_fused", "ug_set_concurrency", "ug_set_fp8_linears", "ug_op_linear_mx8", "ug_set_ff_fused", "ug_op_ff", "ug_op_ln_ff", "ug_op_ln_linear", "ug_bench_ff", "ug_bench_flash", "ug_tune_flash", "ug_tune_ff",
     "ug_eval_depth", "ug_eval_normal", "ug_clip_embed", "ug_vae_encode", "ug_vae_decode", "ug_unet_forward", "ug_normals_from_depth",
     "ug_op_linear", "ug_op_conv", "ug_op_groupnorm", "ug_op_layernorm", "ug_op_flash_attn",
-    "ug_op_temporal_attn", "ug_op_attention_generic", "ug_op_euler_step",
+    "ug_op_temporal_attn", "ug_op_attention_generic", "ug_op_flash_attn_dh", "ug_op_euler_step",
     "ug_bind_stablenormal", "ug_sn_run", "ug_sn_unet_forward", "ug_sn_dino", "ug_sn_vae_decode", "ug_sn_vae_encode", "ug_resize_bilinear",
     "ug_profile_begin", "ug_profile_begin_shapes", "ug_profile_end", "ug_bench_gemm", "ug_bench_groupnorm", "ug_tune_force",
 ]
@@ -112,6 +112,7 @@ def load_library():
     lib.ug_op_flash_attn.argtypes = [vp, vp, ip, ip, ip, vp]
     lib.ug_op_temporal_attn.argtypes = [vp, vp, ip, ip, ip, vp]
     lib.ug_op_attention_generic.argtypes = [vp, vp, ip, ip, ip, ip, vp]
+    lib.ug_op_flash_attn_dh.argtypes = [vp, vp, ip, ip, ip, ip, vp]
     lib.ug_op_euler_step.argtypes = [vp, vp, vp, C.c_long, C.c_float, C.c_float]
     lib.ug_bind_stablenormal.argtypes = [vp, C.POINTER(UNetConfigC), C.POINTER(VAEConfigC), C.POINTER(CLIPConfigC)]
     lib.ug_sn_run.argtypes = [vp, vp, ip, ip, ip, vp, C.c_float, ip, vp, vp, vp, vp]
@@ -490,6 +491,11 @@ class Engine:
     def op_attention_generic(self, qkv, B, S, H, d):
         q = _f32(qkv); out = np.empty((B * S, H * d), np.float32)
         self._ck(self.lib.ug_op_attention_generic(self.ctx, _ptr(q), B, S, H, d, _ptr(out)))
+        return out
+
+    def op_flash_attn_dh(self, qkv, B, S, H, d):
+        q = _f32(qkv); out = np.empty((B * S, H * d), np.float32)
+        self._ck(self.lib.ug_op_flash_attn_dh(self.ctx, _ptr(q), B, S, H, d, _ptr(out)))
         return out
 
     def op_euler_step(self, v, lat, sigma, sigma_next):

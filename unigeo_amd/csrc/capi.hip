@@ -831,6 +831,18 @@ int ug_op_attention_generic(ug_ctx* x, const float* qkv, int B, int S, int H, in
   });
 }
 
+int ug_op_flash_attn_dh(ug_ctx* x, const float* qkv, int B, int S, int H, int d, float* out) {
+  UG_TRY(x, {
+    Ctx& c = x->c; Scope sc(c);
+    const int C = H * d; const long M = (long)B * S;
+    f16* dq = up16(c, qkv, M * 3 * C); f16* o = c.ws.get<f16>(M * C);
+    FlashP p; p.Q = dq; p.K = dq + C; p.V = dq + 2 * C; p.ldq = p.ldk = p.ldv = 3 * C; p.O = o; p.ldo = C; p.B = B; p.H = H; p.S = S;
+    p.scale = 1.0f / sqrtf((float)d);
+    launch_flash_attn_dh(p, d, c.stream);
+    down16(c, o, out, M * C);
+  });
+}
+
 int ug_tune_force(ug_ctx* x, int cfg, int split) {
   if (!x) return -1;
   if (cfg <= -100) x->c.tune.knobs = -cfg - 100;             // knob mask: ug_tune_force(ctx, -100 - knobs, 0)

@@ -157,6 +157,8 @@ struct FlashP {
                       // workgroup order, 4 = 2-slot K/V ring + 4 workgroups per CU
 };
 void launch_flash_attn64(const FlashP& p, hipStream_t s);
+bool flash_attn_dh_supported(int d);
+void launch_flash_attn_dh(const FlashP& p, int d, hipStream_t s);   // self-attention with head dim d in {32, 48, 80, 96, 112, 128} (CLIP ViT-H/14: 80)
 void flash_set_variant(int v);   // test aid: the process default of FlashP::variant (ug_tune_flash)
 
 // Temporal self-attention: for every pixel p and head h, sequence over the T frames

@@ -1462,7 +1462,14 @@ f16* clip_embed(Ctx& c, const f16* video_m11, int T, int H, int W) {
   for (auto& l : m.layers) {
     layernorm(c, y, M, l.ln1, t1);
     linear(c, t1, M, l.qkv, qkv);
-    unfused_attention(c, qkv, 3 * d, T, S, cfg.heads, d / cfg.heads, ao, d);
+    const int dh = d / cfg.heads;
+    if (dh != 64 && flash_attn_dh_supported(dh) && !getenv("UG_CLIP_UNFUSED")) {
+      // round 3: ViT-H/14 has 16 heads of 80 - one fused kernel instead of Q K^T batch + row softmax + V transpose + P V batch (~160 us per layer)
+      FlashP fp; fp.Q = qkv; fp.K = qkv + d; fp.V = qkv + 2 * d; fp.ldq = fp.ldk = fp.ldv = 3 * d; fp.O = ao; fp.ldo = d;
+      fp.B = T; fp.H = cfg.heads; fp.S = S; fp.scale = 1.0f / sqrtf((float)dh);
+      ProfScope ps(c, "flash_attn_clip", 4.0 * T * cfg.heads * (double)S * S * dh, 0);
+      launch_flash_attn_dh(fp, dh, c.stream);
+    } else unfused_attention(c, qkv, 3 * d, T, S, cfg.heads, dh, ao, d);
     { Epi e; e.R1 = y; linear(c, ao, M, l.out, y2, e); }
     layernorm(c, y2, M, l.ln2, t1);
     { Epi e; e.act = UG_ACT_GELU; linear(c, t1, M, l.fc1, mid, e); }

@@ -355,6 +355,142 @@ void launch_flash_attn64(const FlashP& p, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Self-attention for head dims other than 64 (round 3): the CLIP ViT-H/14 tower has 16 heads of 80.  Until now those layers ran as
+// four launches (Q K^T GEMM batch at 57 TFLOP/s, row softmax, V transpose, P V GEMM batch: ~160 us per layer, 7 ms per clip); this is the
+// same online-softmax scheme as flash_attn64_kernel for DH = 16 * NC <= 128, written for brevity, not for the last cycle (S = 257 here):
+// K / V tiles of 64 keys are copied to LDS by plain loads (rows padded to 128 halves, no swizzle, single buffer), scores transposed
+// (S^T = K Q^T, 32x32x16 MFMA, NC chained steps), P^T straight into O^T = V^T P^T over ceil(DH / 32) d tiles (the tile beyond DH multiplies
+// zero-filled padding and is never stored).
+// ------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void flash_attn_dh_kernel(const FlashP p, int nqb) {
+  constexpr int NC = DH / 16, RL = 128, NDT = (DH + 31) / 32, CPR = DH / 8;   // K chunks of 16, LDS row length (halves), d tiles, 16-byte chunks per row
+  __shared__ __attribute__((aligned(16))) f16 Ks[FA_KV * RL];
+  __shared__ __attribute__((aligned(16))) f16 Vs[FA_KV * RL];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bx = blockIdx.x % nqb, bh = blockIdx.x / nqb;
+  const int h = bh % p.H, b = bh / p.H;
+  const int q0 = bx * 128 + wave * 32;
+  const long row0 = (long)b * p.S;
+  const int qi = lane & 31, hh = lane >> 5;
+  const int L = lane & 15, db = ((lane >> 4) & 1) * 16;
+  const float sc = p.scale * 1.4426950408889634f;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < FA_KV * RL / 8; i += 256) {       // zero the padding once (columns >= DH are read by the last d tile)
+    *(f16x8*)(Ks + i * 8) = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    *(f16x8*)(Vs + i * 8) = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  const bool qok = (q0 + qi) < p.S;
+  f16x8 qf[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+    qf[c] = qok ? *(const f16x8*)(p.Q + (row0 + q0 + qi) * p.ldq + h * DH + c * 16 + hh * 8) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  f32x16 o[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) o[dt] = zero16;
+  float m_run = -1e30f, l_run = 0.f;
+  const int ntile = (p.S + FA_KV - 1) / FA_KV;
+  for (int t = 0; t < ntile; ++t) {
+    const int kv0 = t * FA_KV;
+    __syncthreads();                                       // everybody is done with the previous tile (and with the zero fill)
+    for (int i = tid; i < FA_KV * CPR; i += 256) {
+      const int r = i / CPR, ch = i - r * CPR;
+      const long krow = (kv0 + r) < p.S ? (kv0 + r) : 0;    // out-of-range keys: any finite row, their scores are masked
+      *(f16x8*)(Ks + r * RL + ch * 8) = *(const f16x8*)(p.K + (row0 + krow) * p.ldk + h * DH + ch * 8);
+      *(f16x8*)(Vs + r * RL + ch * 8) = *(const f16x8*)(p.V + (row0 + krow) * p.ldv + h * DH + ch * 8);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int row = kb * 32 + qi;
+      f32x16 s = zero16;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const f16x8 kf = *(const f16x8*)(Ks + row * RL + c * 16 + hh * 8);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[c], s, 0, 0, 0);
+      }
+      float mx = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (key >= p.S) s[r] = -1e30f;
+        mx = fmaxf(mx, s[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run, mx * sc);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      m_run = m_new;
+      f16x8 pb[2];
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -m_run));
+        ps += e;
+        pb[r >> 3][r & 7] = (f16)e;
+      }
+      l_run += ps;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+          f16x8 va;
+#pragma unroll
+          for (int hq = 0; hq < 2; ++hq) {
+            const int vrow = kb * 32 + 16 * a + 8 * hq + 4 * hh + (L >> 2);
+            const int col = dt * 32 + db + (L & 3) * 4;
+            const f16x4 tq = lds_tr16(Vs + vrow * RL + col);
+            va[4 * hq + 0] = tq[0]; va[4 * hq + 1] = tq[1]; va[4 * hq + 2] = tq[2]; va[4 * hq + 3] = tq[3];
+          }
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pb[a], o[dt], 0, 0, 0);
+        }
+    }
+  }
+  float l = l_run;
+  l += __shfl_xor(l, 32);
+  const float inv = 1.0f / l;
+  if (qok) {
+    f16* dst = p.O + (row0 + q0 + qi) * p.ldo + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int d0 = dt * 32 + 8 * r4 + 4 * hh;
+        if (d0 < DH) {
+          f16x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (f16)(o[dt][r4 * 4 + e] * inv);
+          *(f16x4*)(dst + d0) = v;
+        }
+      }
+  }
+}
+
+bool flash_attn_dh_supported(int d) { return d == 80 || d == 96 || d == 128 || d == 32 || d == 48 || d == 112; }
+
+void launch_flash_attn_dh(const FlashP& p, int d, hipStream_t s) {
+  UG_REQUIRE(flash_attn_dh_supported(d) && p.S >= 1 && p.B >= 1 && p.H >= 1 && !p.Sk && !p.kv_shared, "flash_attn_dh: self-attention, head dim a supported multiple of 16");
+  UG_REQUIRE(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0, "flash_attn_dh strides");
+  const int nqb = cdiv(p.S, 128);
+  const long total = (long)nqb * p.H * p.B;
+  UG_REQUIRE(total < (1L << 31), "flash_attn_dh grid");
+  switch (d) {
+    case 32: hipLaunchKernelGGL(flash_attn_dh_kernel<32>, dim3((unsigned)total), dim3(256), 0, s, p, nqb); break;
+    case 48: hipLaunchKernelGGL(flash_attn_dh_kernel<48>, dim3((unsigned)total), dim3(256), 0, s, p, nqb); break;
+    case 80: hipLaunchKernelGGL(flash_attn_dh_kernel<80>, dim3((unsigned)total), dim3(256), 0, s, p, nqb); break;
+    case 96: hipLaunchKernelGGL(flash_attn_dh_kernel<96>, dim3((unsigned)total), dim3(256), 0, s, p, nqb); break;
+    case 112: hipLaunchKernelGGL(flash_attn_dh_kernel<112>, dim3((unsigned)total), dim3(256), 0, s, p, nqb); break;
+    default: hipLaunchKernelGGL(flash_attn_dh_kernel<128>, dim3((unsigned)total), dim3(256), 0, s, p, nqb); break;
+  }
+  UG_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------
 // temporal attention: sequence = the T frames of one pixel; one wave per (pixel, head).
 // ------------------------------------------------------------------------------------------
 // NB = number of 32-frame blocks (1: T <= 32 ... 4: T <= 128).  Each wave handles one (pixel, head): all NB*32 key rows'
