@@ -43,7 +43,8 @@ static inline int ug_dev_slot() { int d = 0; (void)hipGetDevice(&d); return d & 
 //   optional nearest-2x upsample of the source, optional channel concat of two sources).
 // ---------------------------------------------------------------------------------------
 enum { UG_ACT_NONE = 0, UG_ACT_SILU = 1, UG_ACT_GELU = 2 };
-enum { UG_F_GEGLU = 1, UG_F_OUT_F32 = 2, UG_F_NOXCD = 4, UG_F_PRIO = 8 /* tuning knob: static priority for the younger half of an 8-wave workgroup */ };
+enum { UG_F_GEGLU = 1, UG_F_OUT_F32 = 2, UG_F_NOXCD = 4, UG_F_PRIO = 8 /* tuning knob: static priority for the younger half of an 8-wave workgroup */,
+       UG_F_R1_F32 = 16 /* R1 points at float32 (ldr1 in floats): the residual stream of the float32-grade VAE encoder, added in the epilogue instead of by a separate pass */ };
 
 struct GemmP {
   const f16* A0; const f16* A1;

@@ -1240,13 +1240,11 @@ static void split_pair(Ctx& c, const float* x, f16* y, long M, int C) {
   ProfScope ps(c, "split_pair", 0, (double)M * C * 8.0);
   launch_split_pair(x, y, M, C, c.stream);
 }
-static void add_f32(Ctx& c, const float* a, const float* b, float* y, long n) {
-  ProfScope ps(c, "add_f32", 0, (double)n * 12.0);
-  launch_add_f32(a, b, y, n, c.stream);
-}
 // conv over a pair tensor [M, 2C] with K-doubled weights -> fp32 [M, cout]
-static void conv_w(Ctx& c, const f16* xpair, int T, int Hi, int Wi, const Conv& cv, int stride, int pad_t, int pad_l, float* out) {
+// res (optional): float32 residual [M, cout] added in the GEMM epilogue (may alias `out`: every element is read and written by the same lane)
+static void conv_w(Ctx& c, const f16* xpair, int T, int Hi, int Wi, const Conv& cv, int stride, int pad_t, int pad_l, float* out, const float* res = nullptr) {
   Epi e; e.flags = UG_F_OUT_F32; e.alg = 0.5f;
+  if (res) { e.R1 = (const f16*)res; e.ldr1 = cv.cout; e.c1 = 1.f; e.flags |= UG_F_R1_F32; }
   conv(c, xpair, cv.cinp, nullptr, 0, T, Hi, Wi, cv, stride, pad_t, pad_l, 1, (f16*)out, e);
 }
 static void res2d_wide(Ctx& c, const Res2D& r, const float* x, int cin, int T, int h, int w, int G, float* out) {
@@ -1257,15 +1255,15 @@ static void res2d_wide(Ctx& c, const Res2D& r, const float* x, int cin, int T, i
   gn32(c, x, T, h * w, G, r.n1, 1, a);
   float* hb = c.ws.get<float>(M * cout);
   conv_w(c, a, T, h, w, r.c1, 1, 1, 1, hb);
-  gn32(c, hb, T, h * w, G, r.n2, 1, a);           // `a` is dead after conv1 (stream order)
-  conv_w(c, a, T, h, w, r.c2, 1, 1, 1, hb);        // hb is dead after the second GroupNorm
   const float* res = x;
-  if (r.has_sc) {
-    split_pair(c, x, a, M, cin);
+  if (r.has_sc) {                                  // 1x1 shortcut of the channel-changing blocks -> out, which then is the residual of conv2
+    split_pair(c, x, a, M, cin);                   // `a` is dead after conv1 (stream order)
     conv_w(c, a, T, h, w, r.sc, 1, 0, 0, out);
     res = out;
   }
-  add_f32(c, hb, res, out, M * cout);
+  gn32(c, hb, T, h * w, G, r.n2, 1, a);
+  // round 3: the float32 residual is added in conv2's epilogue (UG_F_R1_F32) - same fp32 sum as the former add_f32 pass, one tensor write + read less
+  conv_w(c, a, T, h, w, r.c2, 1, 1, 1, out, res);
   c.ws.release(mk);
 }
 static void vattn_wide(Ctx& c, const VAttn& at, const float* x, int T, int hw, int G, float* out) {
@@ -1297,9 +1295,7 @@ static void vattn_wide(Ctx& c, const VAttn& at, const float* x, int T, int hw, i
   q.sA_o = (long)S * 3 * Spad; q.sW_o = (long)C * 3 * Spad; q.sO_o = (long)S * C;
   run_gemm(c, q, T, "gemm_attn_pv", 1.f / 3.f);
   split_pair(c, ao, xn, M, C);
-  float* o = c.ws.get<float>(M * C);
-  { Epi e; e.flags = UG_F_OUT_F32; e.alg = 0.5f; linear(c, xn, M, at.out, (f16*)o, e); }
-  add_f32(c, o, x, out, M * C);
+  { Epi e; e.flags = UG_F_OUT_F32 | UG_F_R1_F32; e.alg = 0.5f; e.R1 = (const f16*)x; e.ldr1 = C; e.c1 = 1.f; linear(c, xn, M, at.out, (f16*)out, e); }   // + float32 residual in the epilogue
   c.ws.release(mk);
 }
 

@@ -205,9 +205,15 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][N
 #pragma unroll
         for (int q = 0; q < CH; ++q) o[q] = p.c0 * v[e + q];
         if (p.R1) {
-          const hvec r = *(const hvec*)(p.R1 + (long)m * p.ldr1 + ob + e);
+          if (p.flags & UG_F_R1_F32) {
+            const float* R = (const float*)p.R1 + (long)m * p.ldr1 + ob + e;
 #pragma unroll
-          for (int q = 0; q < CH; ++q) o[q] += p.c1 * (float)r[q];
+            for (int q = 0; q < CH; q += 4) { const f32x4 r = *(const f32x4*)(R + q); o[q] += p.c1 * r[0]; o[q + 1] += p.c1 * r[1]; o[q + 2] += p.c1 * r[2]; o[q + 3] += p.c1 * r[3]; }
+          } else {
+            const hvec r = *(const hvec*)(p.R1 + (long)m * p.ldr1 + ob + e);
+#pragma unroll
+            for (int q = 0; q < CH; ++q) o[q] += p.c1 * (float)r[q];
+          }
         }
         if (p.R2) {
           const hvec r = *(const hvec*)(p.R2 + (long)m * p.ldr2 + ob + e);
@@ -238,7 +244,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][N
         const int n = ob + e;
         if (n < Nout) {
           float o = p.c0 * v[e];
-          if (p.R1) o += p.c1 * (float)p.R1[(long)m * p.ldr1 + n];
+          if (p.R1) o += p.c1 * ((p.flags & UG_F_R1_F32) ? ((const float*)p.R1)[(long)m * p.ldr1 + n] : (float)p.R1[(long)m * p.ldr1 + n]);
           if (p.R2) o += p.c2 * (float)p.R2[(long)m * p.ldr2 + n];
           if (p.act == UG_ACT_SILU) o = silu_f(o);
           else if (p.act == UG_ACT_GELU) o = gelu_f(o);
