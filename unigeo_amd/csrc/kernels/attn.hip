@@ -394,7 +394,8 @@ __global__ __launch_bounds__(256) void flash_attn_dh_kernel(const FlashP p, int 
   for (int t = 0; t < ntile; ++t) {
     const int kv0 = t * FA_KV;
     __syncthreads();                                       // everybody is done with the previous tile (and with the zero fill)
-    for (int i = tid; i < FA_KV * CPR; i += 256) {
+    const int nrow = min(FA_KV, ((p.S - kv0 + 31) >> 5) << 5);     // whole 32-key blocks that hold at least one valid key (S = 257: the last tile is one block)
+    for (int i = tid; i < nrow * CPR; i += 256) {
       const int r = i / CPR, ch = i - r * CPR;
       const long krow = (kv0 + r) < p.S ? (kv0 + r) : 0;    // out-of-range keys: any finite row, their scores are masked
       *(f16x8*)(Ks + r * RL + ch * 8) = *(const f16x8*)(p.K + (row0 + krow) * p.ldk + h * DH + ch * 8);
@@ -403,6 +404,7 @@ __global__ __launch_bounds__(256) void flash_attn_dh_kernel(const FlashP p, int 
     __syncthreads();
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+      if (kv0 + kb * 32 >= p.S) break;                       // a 32-key block without a valid key (uniform)
       const int row = kb * 32 + qi;
       f32x16 s = zero16;
 #pragma unroll
