@@ -312,7 +312,7 @@ def test_groupnorm_full_size(engine):
 @pytest.mark.parametrize("T,HW,C0,C1,temporal", [
     (25, 3072, 320, 0, False), (25, 3072, 320, 0, True), (25, 768, 640, 0, False), (25, 768, 640, 640, True),
     (25, 192, 1280, 0, False), (25, 192, 1280, 1280, False), (25, 48, 1280, 1280, True), (25, 48, 1280, 0, False),
-    (3, 100, 64, 32, False), (64, 12, 32, 0, True)])
+    (3, 100, 64, 32, False), (64, 12, 32, 0, True), (25, 768, 640, 640, False), (1, 256, 1280, 0, False), (8, 768, 512, 0, False)])
 def test_groupnorm_unet_shapes_two_sources(engine, T, HW, C0, C1, temporal):
     """Every (level, concat, pooled) GroupNorm shape of the UNet, both launch schemes' territory; repeated results must be
     bit-identical (fixed reduction order)."""

@@ -292,6 +292,103 @@ __global__ __launch_bounds__(256) void gn_small(const GroupNormP p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Round 3, slab form: ONE launch, ONE read, no hand-off.  A workgroup owns one group of one frame (or of all frames: temporal variant) and
+// keeps its whole slab in REGISTERS: <= VMAX 4-channel vectors per thread, all loads issued before the first use (one memory round trip
+// instead of one per loop iteration), statistics as an exact two-pass over the registers (mean, then sum of squared deviations; wave
+// butterfly + fixed-order combine of the wave partials => deterministic), normalise + SiLU from the registers.  Thread (row r, vector v):
+// vpg = cpg / 4 neighbouring lanes read one row's cpg channels, NT / vpg rows per step.  Replaces gn_small's two strided passes on the
+// low-resolution levels (12 MB tensors: 19.5 -> ~8 us) and the three launches of the temporal (pooled) variant there (20 - 29 us).
+// ------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ float gn_block_sum(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();                       // red is reused by the second reduction
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) t += red[w];
+  return t;
+}
+
+template <int NT, int VMAX>
+__global__ __launch_bounds__(NT) void gn_slab(const GroupNormP p) {
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  __shared__ float red[NT / 64];
+  const int C = p.C0 + p.C1, cpg = C / p.G, vpg = cpg / 4;
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const long row0 = p.temporal ? 0 : (long)blockIdx.y * p.HW;
+  const int R = p.temporal ? p.T * p.HW : p.HW;
+  const int rpi = NT / vpg;
+  const int rsub = tid / vpg, v = tid - rsub * vpg;
+  const bool act = rsub < rpi;
+  const int c = g * cpg + v * 4;
+  // buffer addressing: per-lane byte offset once, the row step as a scalar offset, rows >= R (and idle lanes) past num_records -> zeros / dropped
+  const bool s0 = g * cpg < p.C0;                          // the group lies in ONE source (C0 % cpg == 0, checked by gn_slab_plan)
+  const int ld = s0 ? p.C0 : p.C1;
+  const f16* base = (s0 ? p.X0 : p.X1) + row0 * ld;
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, R * ld * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Y + row0 * C), 0, R * C * 2, 0x00020000);
+  const int voff = act ? (rsub * ld + (s0 ? c : c - p.C0)) * 2 : 0x7fffffff;
+  const int yoff = act ? (rsub * C + c) * 2 : 0x7fffffff;
+  const int stepx = rpi * ld * 2, stepy = rpi * C * 2;
+  f16x4 x[VMAX];
+#pragma unroll
+  for (int k = 0; k < VMAX; ++k) x[k] = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rX, voff, k * stepx, 0));
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < VMAX; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += (float)x[k][e];
+  const double n = (double)R * cpg;
+  const float mean = (float)((double)gn_block_sum<NT>(s, red) / n);
+  // keep the slab PACKED between the passes (the compiler would otherwise hold the fp32 images: twice the registers)
+#pragma unroll
+  for (int k = 0; k < VMAX; ++k) asm volatile("" : "+v"(x[k]));
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < VMAX; ++k)
+    if (act && rsub + k * rpi < R) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = (float)x[k][e] - mean; q += d * d; }
+    }
+  const float rstd = (float)(1.0 / sqrt((double)gn_block_sum<NT>(q, red) / n + (double)p.eps));
+#pragma unroll
+  for (int k = 0; k < VMAX; ++k) asm volatile("" : "+v"(x[k]));
+  const f16x4 ga = *(const f16x4*)(p.gamma + (act ? c : 0)), be = *(const f16x4*)(p.beta + (act ? c : 0));
+  float a[4], b[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { a[e] = rstd * (float)ga[e]; b[e] = (float)be[e] - mean * a[e]; }
+#pragma unroll
+  for (int k = 0; k < VMAX; ++k) {
+    f16x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float f = (float)x[k][e] * a[e] + b[e];
+      if (p.silu) f = silu_f(f);
+      y[e] = (f16)f;
+    }
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, y), rY, yoff, k * stepy, 0);   // rows >= R: out of range, dropped
+  }
+}
+
+// slab-form plan: threads per workgroup and register vectors per thread, 0 = does not fit
+static inline int gn_slab_plan(const GroupNormP& p, int& vmax) {
+  const int C = p.C0 + p.C1, cpg = C / p.G;
+  if (cpg % 4 || p.C0 % cpg || !p.gamma || !p.beta || cpg / 4 > 64) return 0;
+  if ((p.temporal ? (long)p.T * p.HW : (long)p.HW) * C * 2 >= (1L << 31)) return 0;
+  const int vpg = cpg / 4;
+  const long R = p.temporal ? (long)p.T * p.HW : p.HW;
+  for (int nt : {256, 1024}) {
+    const long k = (R + nt / vpg - 1) / (nt / vpg);
+    const int cap = nt == 256 ? 8 : 48;
+    if (k <= cap) { vmax = k <= 4 ? 4 : k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : 48; return nt; }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // Round 3: ONE launch, ONE read.  A [T*HW, C] activation of the UNet (<= ~50 MB at level 0) fits in the register files of the chip, so a
 // workgroup keeps its rows in registers across the statistics hand-off instead of reading them a second time:
 //   1. load rows -> registers (<= GNF_VPT 8-channel vectors per thread), per-group partial sums -> global (write-through stores);
@@ -497,7 +594,8 @@ size_t groupnorm_ws_floats(int T, int HW, int C, int G) {
   return three > one ? three : one;
 }
 
-// Launch scheme (p.mode 0 = pick, 1 / 2 force; tools/bench_groupnorm.py, profiles/r01_groupnorm_variants.txt):
+// Launch scheme (p.mode 0 = pick, 1 / 2 / 3 / 4 force; tools/bench_groupnorm.py, profiles/r01_groupnorm_variants.txt):
+//   4: gn_slab, one workgroup per (group, frame) with the slab in registers (round 3; replaces 2 wherever it fits)
 //   1: gn_stats / gn_finalize / gn_apply   2: gn_small, one workgroup per (group, frame) - wins on the low-resolution levels,
 //      loses when a row contributes < 64 B to a group and there are many rows (T25 x HW768 x C640: 47 vs 28 us).
 // Also measured and removed: apply with an in-block finalize (2 launches; +3.5 us of serial latency per workgroup, no
@@ -514,10 +612,36 @@ void launch_groupnorm(const GroupNormP& p, hipStream_t s) {
   int mode = p.mode;
   int fch = 0, frpc = 0;
   const bool fused_ok = gn_fused_plan(p, fch, frpc);
-  if (mode == 0) mode = (small_ok && slab <= 16384 && (p.HW <= 256 || cpg >= 32)) ? 2 : (fused_ok ? 3 : 1);
+  int svmax = 0;
+  const int snt = gn_slab_plan(p, svmax);
+  if (mode == 0) {
+    // tools/bench_groupnorm.py, profiles/r03_groupnorm_slab.txt: the register-slab form wins wherever gn_small did (T25 x HW192 x C1280 12.2 vs
+    // 16.5 us, x C2560 19.7 vs 27.4, T1 x HW256 x C1280 5.9 vs 10.9) and up to 64 K elements per slab when a row gives a group >= 64 B and
+    // the grid fills the chip (T25 x HW768 x C1280 38.7 vs 41.4); pooled (temporal) slabs have only G workgroups: 3 launches stay faster
+    const bool narrow_ok = p.HW <= 256 || cpg >= 32;
+    static const bool noslab = getenv("UG_GN_NOSLAB") != nullptr;   // A/B aid
+    if (small_ok && slab <= 16384 && narrow_ok) mode = (snt && !noslab) ? 4 : 2;
+    else if (!p.temporal && snt && svmax <= 16 && narrow_ok && p.G * p.T >= 256 && !noslab) mode = 4;
+    else mode = fused_ok ? 3 : 1;
+  }
+  if (mode == 4 && !snt) mode = p.temporal ? 1 : 2;
   if (mode == 2 && !small_ok) mode = 1;
   if (mode == 3 && !fused_ok) mode = 1;
-  if (mode == 3) {
+  if (mode == 4) {
+    const dim3 grid(p.G, p.temporal ? 1 : p.T);
+    if (snt == 256) {
+      if (svmax <= 4) hipLaunchKernelGGL((gn_slab<256, 4>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((gn_slab<256, 8>), grid, dim3(256), 0, s, p);
+    } else {
+      switch (svmax) {
+        case 4: hipLaunchKernelGGL((gn_slab<1024, 4>), grid, dim3(1024), 0, s, p); break;
+        case 8: hipLaunchKernelGGL((gn_slab<1024, 8>), grid, dim3(1024), 0, s, p); break;
+        case 16: hipLaunchKernelGGL((gn_slab<1024, 16>), grid, dim3(1024), 0, s, p); break;
+        case 32: hipLaunchKernelGGL((gn_slab<1024, 32>), grid, dim3(1024), 0, s, p); break;
+        default: hipLaunchKernelGGL((gn_slab<1024, 48>), grid, dim3(1024), 0, s, p); break;
+      }
+    }
+  } else if (mode == 3) {
     const GnGeom gg = gn_geom(C);
     const size_t lds = std::max((size_t)gg.rpi * C * 2 * sizeof(float), (size_t)p.G * 2 * sizeof(float));
     float* part = p.ws;
