@@ -215,7 +215,7 @@ int ug_bench_gemm(ug_ctx* ctx, int M, int N, int K, int conv, int T, int Hi, int
                   int stride, int ups, int cfg, int split, int iters, float* ms_out);
 int ug_tune_force(ug_ctx* ctx, int cfg, int split);   /* test / A-B aid, per context: force a GEMM tile config (cfg >= 0) and split-K factor for this context's launches, (-1, -1) = planner; cfg = -100 - mask sets the knob mask (kernels/gemm.hip) */
 int ug_tune_ff(int variant);      /* A/B aid: fused feed-forward kernel variant, 1 = GEGLU of chunk j software-pipelined into the MFMAs of chunk j + 1 (default), 0 = the round-2 kernel; bit-identical outputs */
-int ug_tune_flash(int variant);   /* test aid: process default of the flash-attention variant mask (bit 0: one softmax step per 64 keys, bit 1: XCD-grouped workgroup order, bit 2: 2-slot ring + 4 workgroups per CU; default 7).  ug_bench_flash passes its variant with the launch and leaves this alone. */
+int ug_tune_flash(int variant);   /* test aid: process default of the flash-attention variant mask (bit 0: one softmax step per 64 keys, bit 1: XCD-grouped workgroup order, bit 2: 2-slot ring + 4 workgroups per CU, bit 4: lazy rescale + dot2 row sums, bit 5: software-pipelined kernel; default 23).  ug_bench_flash passes its variant with the launch and leaves this alone. */
 
 /* HIP-event profiling of everything launched between begin and end; end returns a JSON
  * object {kernel_family: {ms, calls, flops, bytes}} valid until the next call on ctx. */

@@ -192,6 +192,29 @@ def test_flash_attention_online_softmax_rescale(engine):
     assert_close(engine.op_flash_attn(qkv, B, H, S), attn_ref(qkv, B, S, H, 64), TOL, "flash rescale")
 
 
+@pytest.mark.parametrize("variant", [3, 7, 23, 39])
+def test_flash_attention_variants(engine, variant):
+    """Every launch form of the d = 64 flash attention (3 = 3-slot ring, 7 = 2-slot ring / 4 workgroups per CU, 23 = + lazy rescale and dot2
+    row sums (the default), 39 = software-pipelined kernel) against the fp32 reference: ragged last tile, single tile, a late huge score
+    (reference moved by more than the lazy threshold in a late tile) and a slowly growing maximum (moved by less than the threshold)."""
+    try:
+        engine.lib.ug_tune_flash(variant)
+        for (B, H, S) in [(2, 2, 64), (1, 1, 100), (2, 3, 257), (1, 2, 1000), (3, 1, 129)]:
+            rng = np.random.default_rng(S + H)
+            qkv = rnd(rng, B * S, 3 * H * 64)
+            assert_close(engine.op_flash_attn(qkv, B, H, S), attn_ref(qkv, B, S, H, 64), TOL, f"flash variant {variant} S={S}")
+        rng = np.random.default_rng(9)
+        S = 256
+        qkv = rnd(rng, S, 192)
+        qkv[:, 64:128][200] = h16(qkv[:, 0:64][5] * 6)
+        assert_close(engine.op_flash_attn(qkv, 1, 1, S), attn_ref(qkv, 1, S, 1, 64), TOL, f"flash variant {variant} late maximum")
+        qkv = rnd(rng, 512, 192)
+        qkv[:, 64:128] = h16(qkv[:, 64:128] * (1.0 + np.arange(512)[:, None] / 128.0))      # keys grow: the row maxima creep up tile by tile
+        assert_close(engine.op_flash_attn(qkv, 1, 1, 512), attn_ref(qkv, 1, 512, 1, 64), TOL, f"flash variant {variant} creeping maximum")
+    finally:
+        engine.lib.ug_tune_flash(23)
+
+
 @pytest.mark.parametrize("T,HW,H", [(25, 12, 2), (5, 7, 1), (1, 4, 1), (32, 3, 2), (33, 5, 1), (50, 9, 2), (64, 4, 1),
                                     (65, 5, 1), (96, 3, 2), (97, 4, 1), (128, 3, 2)])   # NB = 3 (65..96 frames) and NB = 4 (97..128, 64 KiB of static LDS)
 def test_temporal_attention(engine, T, HW, H):
