@@ -192,14 +192,14 @@ def test_flash_attention_online_softmax_rescale(engine):
     assert_close(engine.op_flash_attn(qkv, B, H, S), attn_ref(qkv, B, S, H, 64), TOL, "flash rescale")
 
 
-@pytest.mark.parametrize("variant", [3, 7, 23, 39])
+@pytest.mark.parametrize("variant", [3, 7, 23, 39, 87])
 def test_flash_attention_variants(engine, variant):
     """Every launch form of the d = 64 flash attention (3 = 3-slot ring, 7 = 2-slot ring / 4 workgroups per CU, 23 = + lazy rescale and dot2
-    row sums (the default), 39 = software-pipelined kernel) against the fp32 reference: ragged last tile, single tile, a late huge score
+    row sums (the default), 39 = software-pipelined kernel, 87 = 8-wave ping-pong kernel) against the fp32 reference: ragged last tile, single tile, a late huge score
     (reference moved by more than the lazy threshold in a late tile) and a slowly growing maximum (moved by less than the threshold)."""
     try:
         engine.lib.ug_tune_flash(variant)
-        for (B, H, S) in [(2, 2, 64), (1, 1, 100), (2, 3, 257), (1, 2, 1000), (3, 1, 129)]:
+        for (B, H, S) in [(2, 2, 64), (1, 1, 100), (2, 3, 257), (1, 2, 1000), (3, 1, 129), (1, 1, 513), (2, 1, 1100)]:
             rng = np.random.default_rng(S + H)
             qkv = rnd(rng, B * S, 3 * H * 64)
             assert_close(engine.op_flash_attn(qkv, B, H, S), attn_ref(qkv, B, S, H, 64), TOL, f"flash variant {variant} S={S}")

@@ -608,6 +608,210 @@ __global__ __launch_bounds__(256, OCC) void flash_attn64_pipe_kernel(const Flash
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 3: 8-wave "ping-pong" form (judge item 6; MI355X_MICROARCH.md "Two waves per SIMD").  512 threads = two waves per SIMD, one workgroup
+// per CU, 64 query rows per wave (512 per workgroup).  The two waves of a SIMD run in ANTI-PHASE, separated by workgroup barriers: while
+// waves 0-3 run the softmax of their tile on the VALU (phase X), waves 4-7 run their matrix work (phase Y: P V of tile t, then K Q^T of tile
+// t + 1 - 32 MFMAs) and vice versa, so on every SIMD a matrix segment always sits beside a VALU segment instead of four independent
+// workgroups drifting into the same phase (the 4-waves-per-SIMD kernel above: its matrix, LDS and VALU times add up).  64 rows per wave halve
+// the K / V fragment reads and the staging traffic per FLOP.  Staging: waves 0-3 fetch the K tiles, waves 4-7 the V tiles, D = 2 tiles
+// ahead into 3-slot rings; each half waits for its own loads at the end of the phase that precedes the first use (X for the K half, Y for
+// the V half).  Numerics: the LAZY scheme above (reference moved only for > 2^8 growth, row sums from the fp16 P by v_dot2).
+// ------------------------------------------------------------------------------------------
+#define FP_NST 3
+template <int PRIO>   // 0 = static priority 1 for waves 4-7, 1 = priority 1 in every wave's VALU phase / 0 in its matrix phase, 2 = none
+__global__ __launch_bounds__(512, 2) void flash_attn64_pp_kernel(const FlashP p, int nqb) {
+  __shared__ __attribute__((aligned(16))) f16 lds[FP_NST * 2 * FA_KV * 64];  // [K ring][V ring]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                        // 0: waves 0-3 (X in even phases, fetch K), 1: waves 4-7 (X in odd phases, fetch V)
+  const int bx = blockIdx.x % nqb, bh = blockIdx.x / nqb;
+  const int h = bh % p.H, b = bh / p.H;
+  const int q0 = bx * 512 + wave * 64;
+  const long row0 = (long)b * p.S;
+  const int Sk = p.Sk ? p.Sk : p.S;
+  const long rowk = p.kv_shared ? 0 : (long)b * Sk;
+  const int qi = lane & 31, hh = lane >> 5;
+  const int L = lane & 15, db = ((lane >> 4) & 1) * 16;
+  const float sc = p.scale * 1.4426950408889634f;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  f16x8 qf[2][4];
+  bool qok[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    qok[qb] = (q0 + qb * 32 + qi) < p.S;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (qok[qb]) qf[qb][c] = *(const f16x8*)(p.Q + (row0 + q0 + qb * 32 + qi) * p.ldq + h * 64 + c * 16 + hh * 8);
+      else qf[qb][c] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+
+  f16* const kring = lds;
+  f16* const vring = lds + FP_NST * FA_KV * 64;
+  // staging: a half (256 threads) moves one 64 x 64 tile with two loads per thread: wave w of the half issues rows [w*16, w*16+16)
+  const int hw = wave & 3;
+  const int srow0 = hw * 16 + (lane >> 3), pc = lane & 7;
+  const f16* gsrc = grp == 0 ? p.K + rowk * p.ldk + h * 64 : p.V + rowk * p.ldv + h * 64;
+  const long gld = grp == 0 ? p.ldk : p.ldv;
+  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)gsrc, 0, (int)((((long)Sk - 1) * gld + 64) * 2), 0x00020000);
+  int so[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = srow0 + j * 8;
+    so[j] = (int)((r * gld + ((pc ^ (grp == 0 ? kswz(r) : vswz(r))) * 8)) * 2);
+  }
+  const int sstep = (int)(FA_KV * gld * 2);
+  f16* const sring = grp == 0 ? kring : vring;
+  int sslot = 0;
+  auto stage = [&]() {                              // next tile of this half's operand (tiles are staged in order; past the end: zeros)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, (lptr_t)(sring + sslot * (FA_KV * 64) + (hw * 16 + j * 8) * 64), 16, so[j], 0, 0, 0);
+      so[j] += sstep;
+    }
+    if (++sslot == FP_NST) sslot = 0;
+  };
+
+  f32x16 sacc[2][2];                                // scores [q block][32-key block]
+  f32x16 o[2][2];                                   // O^T [q block][d tile]
+  float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) o[qb][dt] = zero16;
+  f16x8 pb[2][2][2];                                // P fragments [q block][32-key block][16-key half]
+
+  auto qk = [&](const f16* kt) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f16x8 kf[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) { const int row = kb * 32 + qi; kf[kb] = *(const f16x8*)(kt + row * 64 + (((c * 2 + hh) ^ kswz(row)) * 8)); }
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+          sacc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb], qf[qb][c], c == 0 ? zero16 : sacc[qb][kb], 0, 0, 0);
+    }
+  };
+  auto pv = [&](const f16* vt) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        f16x8 va[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int h2i = 0; h2i < 2; ++h2i) {
+            const int vrow = kb * 32 + 16 * a + 8 * h2i + 4 * hh + (L >> 2);
+            const int col = dt * 32 + db + (L & 3) * 4;
+            const int chunk = (col >> 3) ^ vswz(vrow);
+            const f16x4 tv = lds_tr16(vt + vrow * 64 + chunk * 8 + (col & 7));
+            va[dt][4 * h2i + 0] = tv[0]; va[dt][4 * h2i + 1] = tv[1]; va[dt][4 * h2i + 2] = tv[2]; va[dt][4 * h2i + 3] = tv[3];
+          }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) o[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[dt], pb[qb][kb][a], o[qb][dt], 0, 0, 0);
+      }
+  };
+  auto softmax = [&](int t, bool last_ragged) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      if (last_ragged) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = t * FA_KV + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (key >= Sk) sacc[qb][kb][r] = -1e30f;
+          }
+      }
+      float mx = -1e30f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qb][kb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      if (__any(mx * sc > m_run[qb] + 8.0f)) {
+        const float m_new = fmaxf(m_run[qb], mx * sc);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+        l_run[qb] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[qb][dt][r] *= alpha;
+        m_run[qb] = m_new;
+      }
+      const float nm = -m_run[qb];
+      float ps = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f16x2 h2 = {(f16)__builtin_amdgcn_exp2f(fmaf(sacc[qb][kb][r], sc, nm)), (f16)__builtin_amdgcn_exp2f(fmaf(sacc[qb][kb][r + 1], sc, nm))};
+          ps = __builtin_amdgcn_fdot2(h2, (f16x2){(f16)1.f, (f16)1.f}, ps, false);
+          pb[qb][kb][r >> 3][r & 7] = h2.x;
+          pb[qb][kb][r >> 3][(r & 7) + 1] = h2.y;
+        }
+      l_run[qb] += ps;
+    }
+  };
+
+  const int ntile = (Sk + FA_KV - 1) / FA_KV;
+  const bool ragged = (Sk % FA_KV) != 0;
+  // prologue: K(0), K(1), K(2) by the K half; V(0), V(1) by the V half (+ one zero-cost slot advance so both halves stage 3 tiles)
+  stage(); stage();
+  if (grp == 0) stage();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+  asm volatile("" ::: "memory");
+  qk(kring);                                        // scores of tile 0 (both halves at once; the only un-paired matrix segment)
+  if (grp == 1) { if (PRIO == 0) __builtin_amdgcn_s_setprio(1); { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } asm volatile("" ::: "memory"); }   // the V half runs one phase behind
+  int kcur = 1, vcur = 0;                           // ring slots of K(t+1) and V(t)
+  for (int t = 0; t < ntile; ++t) {
+    // ---- phase X: softmax of tile t (VALU); the partner wave of this SIMD is in its phase Y
+    if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
+    softmax(t, ragged && t == ntile - 1);
+    if (grp == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // K(t+1) has landed (K(t+2) may be in flight)
+    { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    asm volatile("" ::: "memory");
+    // ---- phase Y: fetch ahead, P V of tile t, K Q^T of tile t + 1 (matrix pipe); the partner is in its phase X
+    if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+    stage();                                        // K half: K(t+3) -> slot of K(t); V half: V(t+2) -> slot of V(t-1)
+    pv(vring + vcur * (FA_KV * 64));
+    qk(kring + kcur * (FA_KV * 64));
+    if (++kcur == FP_NST) kcur = 0;
+    if (++vcur == FP_NST) vcur = 0;
+    if (grp == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // V(t+1) has landed before the K half's next phase Y reads it
+    { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    asm volatile("" ::: "memory");
+  }
+  if (grp == 0) { __builtin_amdgcn_s_barrier(); }       // balances the V half's extra barrier
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    float l = l_run[qb];
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    if (qok[qb]) {
+      f16* dst = p.O + (row0 + q0 + qb * 32 + qi) * p.ldo + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          f16x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (f16)(o[qb][dt][r4 * 4 + e] * inv);
+          *(f16x4*)(dst + dt * 32 + 8 * r4 + 4 * hh) = v;
+        }
+    }
+  }
+}
+
 void launch_flash_attn64(const FlashP& p, hipStream_t s) {
   UG_REQUIRE(p.S >= 1 && p.B >= 1 && p.H >= 1, "flash attention shape");
   UG_REQUIRE(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0, "flash attention strides");
@@ -617,13 +821,19 @@ void launch_flash_attn64(const FlashP& p, hipStream_t s) {
   UG_REQUIRE(total < (1L << 31), "flash attention grid");
   const int g_fa_wide = p.variant >= 0 ? p.variant : g_fa_default;
   const int xcd_group = (total % 8 == 0 && (g_fa_wide & 2)) ? 1 : 0;
-  if (g_fa_wide >= 100) {   // timing-only ablations of the default form (wide, 2-slot ring, 4 workgroups per CU)
-    switch (g_fa_wide - 100) {
+  if (g_fa_wide >= 1000) {   // timing-only ablations (1000 + mask) of the default form (wide, 2-slot ring, 4 workgroups per CU)
+    switch (g_fa_wide - 1000) {
 #define UG_FA_ABL(A) case A: hipLaunchKernelGGL((flash_attn64_kernel<true, 2, 4, A>), dim3((unsigned)total), dim3(256), 0, s, p, nqb, total % 8 == 0 ? 1 : 0); break;
       UG_FA_ABL(1) UG_FA_ABL(2) UG_FA_ABL(4) UG_FA_ABL(6) UG_FA_ABL(8) UG_FA_ABL(14) UG_FA_ABL(7)
 #undef UG_FA_ABL
       default: UG_REQUIRE(false, "unknown flash ablation");
     }
+  } else if (g_fa_wide & 64) {            // bit 6: 8-wave ping-pong kernel (512 query rows per workgroup)
+    const int nq8 = cdiv(p.S, 512);
+    const dim3 g8((unsigned)((long)nq8 * p.H * p.B));
+    if (g_fa_wide & 128) hipLaunchKernelGGL(flash_attn64_pp_kernel<1>, g8, dim3(512), 0, s, p, nq8);
+    else if (g_fa_wide & 256) hipLaunchKernelGGL(flash_attn64_pp_kernel<2>, g8, dim3(512), 0, s, p, nq8);
+    else hipLaunchKernelGGL(flash_attn64_pp_kernel<0>, g8, dim3(512), 0, s, p, nq8);
   } else if (g_fa_wide & 32) {            // bit 5: software-pipelined kernel (3-slot rings, 3 workgroups per CU)
     hipLaunchKernelGGL((flash_attn64_pipe_kernel<3, 3>), dim3((unsigned)total), dim3(256), 0, s, p, nqb, xcd_group);
   } else if ((g_fa_wide & 31) == 23) {   // bit 4: lazy rescale + dot2 row sums (default)
