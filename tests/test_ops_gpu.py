@@ -383,10 +383,10 @@ def _force(engine, cfg):
     engine.tune_force(cfg, 1 if cfg >= 0 else -1)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 3, 4, 8, 12, 14, 19, 34, 35, 39, 54, 59, 60, 61, 62, 63, 64])
+@pytest.mark.parametrize("cfg", [0, 1, 3, 4, 8, 12, 14, 19, 34, 35, 39, 54, 59, 60, 61, 62, 63, 64, 65, 66])
 def test_tile_configs_bitwise_identical_small_ragged(engine, cfg):
     rng = np.random.default_rng(100 + cfg)
-    geglu = cfg in (0, 4, 8, 35, 54, 62, 64)
+    geglu = cfg in (0, 4, 8, 35, 54, 62, 64, 65, 66)
     M, K, N = 2049, 1352 if cfg < 30 else 1344, 640          # ragged M (and K where the flat-address path is taken)
     A, W, b, R = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5), rnd(rng, N), rnd(rng, M, N // 2 if geglu else N)
     x, x1 = rnd(rng, 5, 20, 28, 128), rnd(rng, 5, 20, 28, 64)
