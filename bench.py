@@ -319,6 +319,8 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
 
     import torch
+    from unigeo_amd.shard import pin_rank_to_cores
+    affinity = pin_rank_to_cores(local, world)            # N ranks x ~25 k launches per clip share one host: each rank keeps its own cores
     dist = None
     multi = world > 1 or a.force_dist
     if multi:
@@ -348,17 +350,23 @@ def main():
     K = np.stack(clip["intrinsics"], 0)
     eng.set_inputs(frames, nl, na, K)                     # inputs resident in HBM before the timed region
 
+    t_clip, t_gather = [], []                              # per-clip wall of this rank: the engine call / the all_gather (N > 1)
+
     def one_clip():
+        t_a = time.perf_counter()
         eng.run(a.denoise_steps, 8, with_normals=False)   # returns after its own stream sync
+        t_b = time.perf_counter()
         if multi:                                          # reassemble outputs: RCCL all_gather over xGMI
             ptr, shape = eng.device_ptrs()["depth"]
             local_t = torch.as_tensor(DeviceArray(ptr, shape), device=f"cuda:{local}")
             out = [torch.empty_like(local_t) for _ in range(world)]
             dist.all_gather(out, local_t)
             torch.cuda.current_stream().synchronize()      # the next run overwrites the engine's depth buffer
+        t_clip.append((t_b - t_a) * 1e3); t_gather.append((time.perf_counter() - t_b) * 1e3)
 
     for _ in range(a.warmup):
         one_clip()
+    t_clip.clear(); t_gather.clear()
     if multi:
         dist.barrier()
     torch.cuda.synchronize() if torch.cuda.is_available() else None
@@ -374,10 +382,15 @@ def main():
     dt = time.perf_counter() - t0
     if smi:
         smi.__exit__()
+    per_rank = None
     if multi:
         tt = torch.tensor([dt], device=f"cuda:{local}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        mine = torch.tensor([float(np.mean(t_clip)), float(np.max(t_clip)), float(np.mean(t_gather)), float(np.max(t_gather))], device=f"cuda:{local}")
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[round(float(v), 2) for v in r.tolist()] for r in allr]
 
     if rank == 0:
         ms = dt / a.steps * 1000.0
@@ -394,6 +407,9 @@ def main():
                           "clips_per_gpu_timed": a.steps, "frames": T, "height": H, "width": W,
                           "denoise_steps": a.denoise_steps, "parallelism": f"clip-sharded x{world}, RCCL all_gather of depth",
                           "lanes": a.lanes}}
+        res["per_rank_ms"] = {"columns": ["clip_mean", "clip_max", "gather_mean", "gather_max"],
+                              "ranks": per_rank if per_rank is not None else [[round(float(np.mean(t_clip)), 2), round(float(np.max(t_clip)), 2), 0.0, 0.0]],
+                              "host_affinity": affinity}
         res["calibration"] = {**calibration_probe(eng), **smi.summary(),
                               "note": "probes run in this process right after the timed clips; sclk / power sampled at 20 Hz during them (None = SMI not readable in this container)"}
         full = (T, H, W, a.denoise_steps) == (25, 384, 512, 25)
@@ -408,7 +424,7 @@ def main():
             ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
             res["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_TFLOPS_F16, 4), "traffic": None,
-                               "kernel": "gemm_kernel<...> + gemm_ws_kernel<...> + gemm_ldr_kernel<...> (all linear / 3x3 / 1x1 / temporal-conv / attention GEMM launches)",
+                               "kernel": "gemm_kernel<...> + gemm_ws_kernel<...> + gemm_ldr_kernel<...> + conv_halo_kernel<...> (all linear / 3x3 / 1x1 / temporal-conv / attention GEMM launches)",
                                "launches": g_calls, "avg_launch_us": round(g_ms * 1000.0 / max(g_calls, 1), 2),
                                "algorithmic_tflop": round(g_fl / 1e12, 2),
                                "note": "algorithmic FLOPs (SURVEY 8d): a nearest-2x upsample + 3x3 conv is credited its 9-tap FLOPs although the "
@@ -458,6 +474,52 @@ def main():
                 res["value_fp8_linears"] = round(rate(2, a.denoise_steps, with_normals=False), 3)
                 eng.set_fp8_linears(False)
             res["vae_encoder"] = "float32-grade (reference force_upcast): fp32 residual stream / norms / softmax, fp16 hi/lo-pair MFMA GEMMs"
+            # BASELINE configs[4] geometry (50-frame 576x768 clips) and configs[3] (StableNormal, one 576x576 image per call) on the SAME line, so
+            # that the driver's clock covers them: 1 warm + 2 timed clips per mode / 1 warm + 5 timed images.  Never a reason to lose the headline.
+            try:
+                T5, H5, W5 = 50, 576, 768
+                clip5 = synthetic_clip(T5, H5, W5, seed=4321)
+                nl5, na5 = make_noise(T5, H5, W5, seed=5)
+                eng.set_inputs(DepthCrafter.prepare_input(None, clip5), nl5, na5, np.stack(clip5["intrinsics"], 0))
+
+                def rate5(n):
+                    eng.run(a.denoise_steps, 8, with_normals=False)
+                    t1 = time.perf_counter()
+                    for _ in range(n):
+                        eng.run(a.denoise_steps, 8, with_normals=False)
+                    return n * T5 / (time.perf_counter() - t1)
+                res["value_c5_50x576x768_fp16"] = round(rate5(2), 3)
+                eng.set_fp8_linears(True)
+                res["value_c5_50x576x768_fp8"] = round(rate5(2), 3)
+                eng.set_fp8_linears(False)
+                res["c5_note"] = ("BASELINE configs[4] geometry on ONE GPU, frames/s: 50-frame 576x768 clips, 25 Euler steps, 3225 TFLOP per clip; "
+                                  "_fp8 = MX-fp8 (e4m3 + e8m0 block scales) transformer linear layers, everything else fp16 (reduced precision, off by default)")
+            except Exception as e:
+                res["c5_note"] = f"configs[4] side rate failed: {e!r}"
+            finally:
+                eng.set_fp8_linears(False)
+                eng.set_inputs(frames, nl, na, K)
+            try:
+                from unigeo_amd.stablenormal import StableNormalPredictorHIP
+                pred = StableNormalPredictorHIP.from_random(seed=7, workspace_bytes=24 << 30)
+                yy, xx = np.mgrid[0:576, 0:576].astype(np.float32)
+                img = np.clip(np.stack([127.5 + 100 * np.sin(xx / 41.0 + c) * np.cos(yy / 29.0) for c in range(3)], -1), 0, 255).astype(np.uint8).astype(np.float32)[None] / 255.0
+                for _ in range(2):
+                    pred.predict_batch(img)
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    pred.predict_batch(img)
+                res["value_stablenormal_576_b1"] = round(5.0 / (time.perf_counter() - t1), 3)
+                pe = pred.engine
+                pe.profile_begin(); pred.predict_batch(img); pr = pe.profile_end()
+                gm = {k: v for k, v in pr.items() if k.startswith("gemm_")}
+                gms, gfl = sum(v["ms"] for v in gm.values()), sum(v["flops"] for v in gm.values())
+                res["stablenormal_576_b1_gemm_frac"] = round(gfl / (gms * 1e-3) / 1e12 / PEAK_TFLOPS_F16, 4) if gms > 0 else None
+                res["stablenormal_note"] = ("BASELINE configs[3]: images/s, one 576x576 image per call (reference model/stablenormal.py:39), YOSO + 10 refinement steps, "
+                                            "host<->device copies inside the call; predictor parity unpinned (DESIGN.md section 9)")
+                pe.close()
+            except Exception as e:
+                res["stablenormal_note"] = f"configs[3] side rate failed: {e!r}"
         res["workspace_peak_gb"] = round(eng.workspace_peak() / 2 ** 30, 2)
         if not a.no_cpu_baseline and world == 1:
             try:

@@ -51,6 +51,38 @@ def test_sharded_run_world2(n_clips):
         assert r == clips_for_rank(n_clips, world, rank)    # clip i on rank i % world
 
 
+def _worker_pinned(rank, world, port, n_clips, q):
+    from unigeo_amd.shard import pin_rank_to_cores
+    cores = pin_rank_to_cores(rank, world)
+    _worker(rank, world, port, n_clips, q)
+    q.put(("cores", rank, cores, sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None))
+
+
+def test_sharded_run_world8_ragged_tail():
+    """BASELINE configs[2] shape of the launch: 8 ranks, 17 clips (two full rounds + a tail round with ONE real clip and seven dummies), every
+    rank pinned to its own slice of the host cores as bench.py / tools/eval_sharded.py do."""
+    world, n_clips, port = 8, 17, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_pinned, args=(r, world, port, n_clips, q)) for r in range(world)]
+    [p.start() for p in ps]
+    got = [q.get(timeout=300) for _ in range(2 * world)]
+    [p.join(60) for p in ps]
+    out = [g for g in got if g[0] != "cores"]
+    pins = {g[1]: (g[2], g[3]) for g in got if g[0] == "cores"}
+    assert all(ok for _, ok, _ in out)
+    assert sorted(i for _, _, r in out for i in r) == list(range(n_clips))
+    for rank, _, r in out:
+        assert r == clips_for_rank(n_clips, world, rank)
+    assert sorted(len(r) for _, _, r in out) == [2] * 7 + [3]            # the tail round has one real clip
+    for rank, (want, have) in pins.items():
+        if want is not None:
+            assert have == want and len(want) >= 1                         # the process really runs on the slice it was given
+    slices = [tuple(w) for w, _ in pins.values() if w is not None]
+    if len(slices) == world and len(set(c for s_ in slices for c in s_)) >= world:
+        assert len(set(slices)) == world                                    # distinct slices when the host has >= world cores
+
+
 def test_partition_helpers():
     assert clips_for_rank(10, 8, 1) == [1, 9] and clips_for_rank(3, 8, 5) == []
     assert rounds(17, 8) == 3 and rounds(8, 8) == 1

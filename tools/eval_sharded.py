@@ -12,6 +12,8 @@ from unigeo_amd.harness.distributed import evaluate_sharded
 cfg = yaml.safe_load(open(sys.argv[1]))
 world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
 multi = world > 1 or os.environ.get("UG_FORCE_DIST") == "1"      # UG_FORCE_DIST=1: take the RCCL path with a single rank (plumbing check)
+from unigeo_amd.shard import pin_rank_to_cores
+pin_rank_to_cores(local, world)                                  # each rank's launch thread keeps its own host cores
 if multi:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29542")
     os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")

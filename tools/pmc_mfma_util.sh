@@ -28,7 +28,7 @@ with open("gpurun_out/pmc_mfma_util.txt", "w") as o:
         if a <= 0: continue
         o.write(f"{fam:40s} {n[fam]:10d} {a / tot_a:7.1%} {busy[fam] / (a * 128):9.1%}\n")
     o.write(f"{'ALL KERNELS':40s} {sum(n.values()):10d} {1:7.1%} {tot_b / (tot_a * 128):9.1%}\n")
-    gem = [f for f in act if f.startswith("gemm_") or f.startswith("ff_fused")]
+    gem = [f for f in act if f.startswith("gemm_") or f.startswith("ff_fused") or f.startswith("conv_halo")]
     o.write(f"{'GEMM family (gemm_* + ff_fused)':40s} {sum(n[f] for f in gem):10d} {sum(act[f] for f in gem) / tot_a:7.1%} {sum(busy[f] for f in gem) / (sum(act[f] for f in gem) * 128):9.1%}\n")
 print(open("gpurun_out/pmc_mfma_util.txt").read())
 PY

@@ -11,6 +11,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 T, H, W = 25, 384, 512
 pipe = DepthCrafterPipelineHIP.from_random(seed=42, workspace_bytes=40 << 30)
 eng = pipe.engine
+if os.environ.get("UG_TUNE_KNOBS"):                       # GEMM knob mask for this run (kernels/gemm.hip), e.g. 16384 = halo conv off
+    eng.tune_force(-100 - int(os.environ["UG_TUNE_KNOBS"]), -1)
 clip = synthetic_clip(T, H, W)
 nl, na = make_noise(T, H, W, 0)
 eng.set_inputs(DepthCrafter.prepare_input(None, clip), nl, na, np.stack(clip["intrinsics"], 0))

@@ -79,6 +79,8 @@ struct GemmP {
   int m_off;             // im2col only, producer / consumer kernel only: this launch covers output rows [m_off, m_off + M) of the convolution
                          // (Out / R1 / R2 already point at row m_off) - row-split launches, see launch_gemm
   int group_m;           // tile walk: 0 / 1 = row-major, g > 1 = g M-tiles x all N tiles column by column (set by launch_gemm; see tile_coord)
+  int halo_tw, halo_lg;  // set by launch_conv_halo only (kernels/conv_halo.hip): the tile is (256 / halo_tw) x halo_tw output pixels of one frame, halo_tw = 1 << halo_lg;
+                         // the epilogue maps tile row r to launch row m0 + (r >> halo_lg) * Wo + (r & (halo_tw - 1))
   int tune_cfg_p1, tune_split_p1, tune_knobs;   // GemmTune of the launching context, + 1 so that a zeroed GemmP means "no override"
 };
 // tuning overrides (A/B tools and the tile-config tests; ug_tune_force sets them on ONE context, the engine copies them into every GemmP):
@@ -89,6 +91,9 @@ void launch_gemm_mx8(const GemmP& p, hipStream_t s);   // dense only; C0 = lda a
 // fp16 [M, K] (row stride ldx) -> e4m3 bytes [M, K] + e8m0 scales (layout above, ld_s >= round_up(M, 256)); K % 128 == 0
 void launch_quant_mx8(const f16* x, long ldx, long M, int K, unsigned char* q, unsigned* scales, long ld_s, hipStream_t s);
 void launch_gemm(const GemmP& p, int batch, hipStream_t s);
+// halo-staged 3x3 convolution (kernels/conv_halo.hip; tile configs 70 / 71 = 256 x 160 / 256 x 128, 72 / 73 = 192 x 128 / 192 x 160 output pixels x columns): stride 1, pad 1, chunk-major weights, whole 256-pixel tiles
+bool conv_halo_supported(const GemmP& p, int batch, int bm, int bn);
+void launch_conv_halo(const GemmP& p, int bm, int bn, hipStream_t s);
 void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out);   // heuristic used when cfg/splitk are 0
 
 // Fused GEGLU feed-forward (kernels/ff_fused.hip): Out = c0 * (GEGLU(X W1^T + b1) W2^T + b2) + c1 R1 + c2 R2, all [M, C] row-major (ld = C);

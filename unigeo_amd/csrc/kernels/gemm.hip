@@ -20,68 +20,7 @@
 #include "../common.h"
 #include <algorithm>
 
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7, far below the fp16 output spacing): ~12 VALU ops + one
-// exp instead of libm's erff - the GEGLU epilogue evaluates it 8x per output row per lane.
-__device__ __forceinline__ float erf_as(float x) {
-  const float ax = fabsf(x);
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
-  const float y = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
-  const float r = 1.0f - y * __expf(-ax * ax);
-  return copysignf(r, x);
-}
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-
-// GEGLU on two (value, gate) pairs in packed fp32 (v_pk_fma/mul/add_f32 issue two lanes' worth per instruction):
-//   h * g * Phi(g),  Phi(g) = 1/2 + sign(g) (1/2 - erfc(|g|/sqrt2)/2),  erfc by the same Abramowitz-Stegun 7.1.26 form as
-// erf_as (coefficients pre-halved, argument scaling folded in).  Per pair of outputs: 2 rcp + 2 exp2 + ~16 VALU instead of
-// ~50 for the scalar form - in the K = 320 projections the epilogue is as long as the K loop, so this is wall time.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 geglu2(f32x2 h, f32x2 g) {
-  const f32x2 ag = {__builtin_fabsf(g.x), __builtin_fabsf(g.y)};
-  const f32x2 u = ag * 0.23164189f + 1.0f;   // 1 + 0.3275911 |g| / sqrt(2)
-  const f32x2 t = {__builtin_amdgcn_rcpf(u.x), __builtin_amdgcn_rcpf(u.y)};
-  f32x2 y = t * 0.5307027145f - 0.7265760135f;
-  y = y * t + 0.7107068705f;
-  y = y * t - 0.142248368f;
-  y = y * t + 0.127414796f;
-  y = y * t;                                   // erfc(|g|/sqrt2) / 2 / exp(-g^2/2)
-  const f32x2 w = (g * g) * -0.72134752044f;   // -g^2/2 * log2(e)
-  const f32x2 e = {__builtin_amdgcn_exp2f(w.x), __builtin_amdgcn_exp2f(w.y)};
-  const f32x2 q = 0.5f - y * e;
-  const f32x2 phi = {0.5f + __builtin_copysignf(q.x, g.x), 0.5f + __builtin_copysignf(q.y, g.y)};
-  return h * g * phi;
-}
-
-// 16-byte-chunk swizzle of a [rows][BK] fp16 LDS tile: makes 16 consecutive rows reading the same logical
-// chunk land on 16 distinct 16-byte slots of the 256-byte bank row.
-template <int BK> __device__ __forceinline__ int swz(int row) {
-  if (BK == 64) return (row >> 1) & 7;   // 128-B rows, 2 rows per bank row
-  else return (row >> 2) & 3;            // 64-B rows, 4 rows per bank row
-}
-
-// Tile id -> (tm, tn).  group_m <= 1: row-major (all N tiles of one M tile are neighbours: the workgroups of an XCD share ONE
-// activation panel - right for im2col, whose A operand is re-read per tap, and for weights that fit the 4 MiB L2).  group_m = g > 1:
-// ids walk g M-tiles x all N tiles column by column, so the ~32 tiles an XCD works on at a time form a g x (32/g) block and touch
-// g + 32/g operand panels instead of 1 + 32 - for dense layers with weights far larger than the L2 the row-major walk re-fetched the
-// whole weight matrix once per M tile (profiles/r02_pmc_traffic_per_shape.txt: 4800x10240x1280 read 524 MB for 88 MB of operands).
-__device__ __forceinline__ void tile_coord(int tile, int ntm, int ntn, int group_m, int& tm, int& tn) {
-  if (group_m <= 1) { tm = tile / ntn; tn = tile - tm * ntn; return; }
-  const int per = group_m * ntn;
-  const int grp = tile / per, local = tile - grp * per;
-  const int first = grp * group_m;
-  const int gm = min(ntm - first, group_m);
-  tn = local / gm;
-  tm = first + (local - tn * gm);
-}
-// + the frame-fastest permutation of the M tiles for temporal convolutions (GemmP::tm_T)
-__device__ __forceinline__ void tile_coord_p(const GemmP& p, int tile, int ntm, int ntn, int& tm, int& tn) {
-  tile_coord(tile, ntm, ntn, p.group_m, tm, tn);
-  if (p.tm_T) { const int q = tm / p.tm_T; tm = (tm - q * p.tm_T) * p.tm_nb + q; }
-}
+#include "gemm_common.h"
 
 // waves per SIMD the LDS footprint allows (workgroups per CU x waves per workgroup / 4 SIMDs): handed to
 // __launch_bounds__ so the register allocator does not trade that occupancy away.
@@ -105,156 +44,6 @@ template <int BM, int BN, int BK, int NST, int WMW, int WNW> struct GemmOcc {
 #else
 #define UG_STAMP(slot) do {} while (0)
 #endif
-
-template <int N> struct HVec;
-template <> struct HVec<8> { typedef f16x8 type; };
-template <> struct HVec<4> { typedef f16x4 type; };
-
-// Per-tile epilogue shared by the GEMM kernels: the lane holds WID = 4*NT contiguous columns of rows
-// m0 + wm*WTM + i*16 + (lane & 15).  Clears the accumulators for the next tile.
-template <int MT, int NT, int WTM, int WTN>
-__device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wm, int wn, int lane,
-                                              long out_off) {
-  constexpr int WID = 4 * NT;
-  constexpr int CH = (WID % 8 == 0) ? 8 : 4;   // vector width of the epilogue's loads / stores (WID = 20: 80-column wave tiles)
-  typedef typename HVec<CH>::type hvec;
-  const int l15 = lane & 15, g = lane >> 4;
-  const bool geglu = (p.flags & UG_F_GEGLU) != 0;
-  const bool of32 = (p.flags & UG_F_OUT_F32) != 0;
-  const int Nout = geglu ? p.N / 2 : p.N;
-  const int OW = geglu ? WID / 2 : WID;        // output columns of this lane
-  const int nb = n0 + wn * WTN + g * WID;      // lane holds WID contiguous columns of its rows
-  if (p.splitk > 1) {   // raw fp32 partials [split][M][N]
-    float* P = p.partial + ((long)blockIdx.y * p.M) * p.N;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int m = m0 + wm * WTM + i * 16 + l15;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n = nb + j * 4;
-        if (m < p.M && n + 4 <= p.N) *(f32x4*)(P + (long)m * p.N + n) = acc[i][j];
-        acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-    }
-    return;
-  }
-  const int ob = geglu ? nb / 2 : nb;          // first output column of this lane
-  const bool full = (nb + WID <= p.N);
-  const bool vec = full && ((p.ldo & 7) == 0) && (!p.R1 || (p.ldr1 & 7) == 0) &&
-                   (!p.R2 || (p.ldr2 & 7) == 0) && (OW % CH == 0);
-  float bv[WID];
-#pragma unroll
-  for (int e = 0; e < WID; ++e) bv[e] = 0.f;
-  if (full) {
-    if (p.bias) {
-#pragma unroll
-      for (int e = 0; e < WID; e += CH) {
-        const hvec b = *(const hvec*)(p.bias + nb + e);
-#pragma unroll
-        for (int q = 0; q < CH; ++q) bv[e + q] += (float)b[q];
-      }
-    }
-    if (p.bias2) {
-#pragma unroll
-      for (int e = 0; e < WID; e += CH) {
-        const hvec b = *(const hvec*)(p.bias2 + nb + e);
-#pragma unroll
-        for (int q = 0; q < CH; ++q) bv[e + q] += (float)b[q];
-      }
-    }
-  } else {
-#pragma unroll
-    for (int e = 0; e < WID; ++e)
-      if (nb + e < p.N) {
-        if (p.bias) bv[e] += (float)p.bias[nb + e];
-        if (p.bias2) bv[e] += (float)p.bias2[nb + e];
-      }
-  }
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int m = m0 + wm * WTM + i * 16 + l15;
-    long orow = m;
-    if (p.up_phase) {   // sub-pixel phase of a nearest-2x upsample conv: scatter to the (2y+a, 2x+b) output pixel
-      const int hw = p.Ho * p.Wo;
-      const int t = m / hw, rem = m - t * hw;
-      const int y = rem / p.Wo, x = rem - y * p.Wo;
-      const int ph = p.up_phase - 1;
-      orow = ((long)t * 2 * p.Ho + 2 * y + (ph >> 1)) * (2 * p.Wo) + 2 * x + (ph & 1);
-    }
-    float v[WID];
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { v[j * 4 + r] = acc[i][j][r] + bv[j * 4 + r]; }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (m >= p.M) continue;
-    if (geglu) {
-      if (WID == 16) {
-#pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-          const f32x2 r = geglu2((f32x2){v[e], v[e + 1]}, (f32x2){v[8 + e], v[9 + e]});
-          v[e] = r.x; v[e + 1] = r.y;
-        }
-      }
-    }
-    if (vec) {
-#pragma unroll
-      for (int e = 0; e < OW; e += CH) {
-        float o[CH];
-#pragma unroll
-        for (int q = 0; q < CH; ++q) o[q] = p.c0 * v[e + q];
-        if (p.R1) {
-          if (p.flags & UG_F_R1_F32) {
-            const float* R = (const float*)p.R1 + (long)m * p.ldr1 + ob + e;
-#pragma unroll
-            for (int q = 0; q < CH; q += 4) { const f32x4 r = *(const f32x4*)(R + q); o[q] += p.c1 * r[0]; o[q + 1] += p.c1 * r[1]; o[q + 2] += p.c1 * r[2]; o[q + 3] += p.c1 * r[3]; }
-          } else {
-            const hvec r = *(const hvec*)(p.R1 + (long)m * p.ldr1 + ob + e);
-#pragma unroll
-            for (int q = 0; q < CH; ++q) o[q] += p.c1 * (float)r[q];
-          }
-        }
-        if (p.R2) {
-          const hvec r = *(const hvec*)(p.R2 + (long)m * p.ldr2 + ob + e);
-#pragma unroll
-          for (int q = 0; q < CH; ++q) o[q] += p.c2 * (float)r[q];
-        }
-        if (p.act == UG_ACT_SILU) {
-#pragma unroll
-          for (int q = 0; q < CH; ++q) o[q] = silu_f(o[q]);
-        } else if (p.act == UG_ACT_GELU) {
-#pragma unroll
-          for (int q = 0; q < CH; ++q) o[q] = gelu_f(o[q]);
-        }
-        if (of32) {
-          float* O = (float*)p.Out + out_off + orow * p.ldo + ob + e;
-#pragma unroll
-          for (int q = 0; q < CH; q += 4) *(f32x4*)(O + q) = (f32x4){o[q], o[q + 1], o[q + 2], o[q + 3]};
-        } else {
-          hvec h;
-#pragma unroll
-          for (int q = 0; q < CH; ++q) h[q] = (f16)o[q];
-          *(hvec*)((f16*)p.Out + out_off + orow * p.ldo + ob + e) = h;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < OW; ++e) {
-        const int n = ob + e;
-        if (n < Nout) {
-          float o = p.c0 * v[e];
-          if (p.R1) o += p.c1 * ((p.flags & UG_F_R1_F32) ? ((const float*)p.R1)[(long)m * p.ldr1 + n] : (float)p.R1[(long)m * p.ldr1 + n]);
-          if (p.R2) o += p.c2 * (float)p.R2[(long)m * p.ldr2 + n];
-          if (p.act == UG_ACT_SILU) o = silu_f(o);
-          else if (p.act == UG_ACT_GELU) o = gelu_f(o);
-          if (of32) ((float*)p.Out)[out_off + orow * p.ldo + n] = o;
-          else ((f16*)p.Out)[out_off + orow * p.ldo + n] = (f16)o;
-        }
-      }
-    }
-  }
-}
 
 // BUFA: operands are fetched with buffer addressing (buffer_load_dwordx4 ... offen lds): the per-lane byte offset of a
 // row is computed once per tile, the K / tap advance is a scalar offset, and out-of-range rows / padding taps point the
@@ -999,7 +788,8 @@ __global__ __launch_bounds__((WMW * WNW + 4) * 64, (WMW * WNW == 8 ? 3 : 2)) voi
 #pragma unroll
         for (int l = 0; l < LA; ++l) {
           const unsigned off = (a_st[l] & 0x7FFFFFu) * (unsigned)Cs2 + ((l & 1) ? lc16_1 : lc16_0);
-          const unsigned voff = ((a_st[l] >> tapbit) & 1u) ? off : SENT;
+          unsigned voff = ((a_st[l] >> tapbit) & 1u) ? off : SENT;
+          if ((p.tune_knobs & 262144) && tapbit != 23) voff = SENT;   // TIMING-ONLY ablation (wrong results): activation rows fetched for ONE tap of nine - what a halo-resident tile would pull through the L2
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(As + (pw * LA + l) * 8 * BK), 16, (int)voff, soff, 0, 0);
         }
         // chunk-major K order (the only one the single-tap-per-K-tile paths take): next tap of the same 64-channel chunk, then the next chunk
@@ -1357,6 +1147,11 @@ static void launch_cfg(int cfg, const GemmP& p, int batch, hipStream_t s) {
              else launch_mode<192, 128, 64, 3, 2, 4>(p, batch, s); break;   // producer / consumer form of 61
     case 64: if (gemm_can_bufa(p, 64, true)) { if (!ring3 && (p.tune_knobs & 131072)) launch_ws<128, 4, 2, 192, 4, true>(p, batch, s); else if (!ring3 && (p.tune_knobs & 65536)) launch_ws<128, 4, 2, 192, 4>(p, batch, s); else launch_ws<128, 4, 2, 192>(p, batch, s); }
              else launch_mode<192, 128, 64, 3, 4, 2>(p, batch, s); break;   // ... of 62
+    // halo-staged 3x3 convolutions (kernels/conv_halo.hip): the activation halo of a 64-channel chunk is fetched once for its nine taps
+    case 70: UG_REQUIRE(conv_halo_supported(p, batch, 256, 160), "config 70: not a halo-stageable convolution"); launch_conv_halo(p, 256, 160, s); break;
+    case 71: UG_REQUIRE(conv_halo_supported(p, batch, 256, 128), "config 71: not a halo-stageable convolution"); launch_conv_halo(p, 256, 128, s); break;
+    case 72: UG_REQUIRE(conv_halo_supported(p, batch, 192, 128), "config 72: not a halo-stageable convolution"); launch_conv_halo(p, 192, 128, s); break;
+    case 73: UG_REQUIRE(conv_halo_supported(p, batch, 192, 160), "config 73: not a halo-stageable convolution"); launch_conv_halo(p, 192, 160, s); break;
     default: UG_REQUIRE(false, "unknown / pruned GEMM tile config");
   }
 }
@@ -1569,9 +1364,10 @@ static int pick_group_m(const GemmP& p, int cfg, int batch, int split) {
     case 12: bm = 64; bn = 64; percu = 5; break;
     case 14: case 34: bm = 256; bn = 64; percu = 2; break;
     case 15: case 35: bm = 256; bn = 256; break;
-    case 60: bm = 256; bn = 160; break;
-    case 61: case 62: case 63: case 64: case 65: bm = 192; bn = 128; break;
-    default: break;                                                    // 4, 8, 19, 39, 54, 59: 256 x 128
+    case 60: case 70: bm = 256; bn = 160; break;
+    case 61: case 62: case 63: case 64: case 65: case 72: bm = 192; bn = 128; break;
+    case 73: bm = 192; bn = 160; break;
+    default: break;                                                    // 4, 8, 19, 39, 54, 59, 71: 256 x 128
   }
   const int ntm = cdiv(p.M, bm), ntn = cdiv(p.N, bn);
   if (ntm < 2 || ntn < 2) return 1;
@@ -1614,6 +1410,7 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
     const long ntn = p.N / 160, tiles = (long)cdiv(p.M, 256) * ntn, whole = tiles / 256 * 256, rem = tiles - whole;
     if (whole > 0 && rem > 0 && rem * 2 <= 256) {
       const int M1 = (int)(whole / ntn) * 256;
+      const bool halo = (p.tune_knobs & 32768) != 0;             // A/B: halo-staged form of both launches (measured slower on the 256 x 160 tile)
       GemmP a = p; a.M = M1; a.cfg_p1 = 61;                     // config 60 (+ 1)
       GemmP b = p0; b.M = p.M - M1; b.m_off = M1; b.Out = (void*)((f16*)p.Out + (long)M1 * p.ldo);
       if (p.flags & UG_F_NOXCD) b.flags |= UG_F_NOXCD;
@@ -1624,12 +1421,29 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
       b.cfg_p1 = cb + 1; b.splitk = 1;
       a.splitk = 1;
       a.group_m = pick_group_m(a, 60, 1, 1); a.tm_T = a.tm_nb = 0;
-      launch_cfg(60, a, 1, s);
+      launch_cfg(halo && conv_halo_supported(a, 1, 256, 160) ? 70 : 60, a, 1, s);
+      if (halo && conv_halo_supported(b, 1, 256, 160)) cb = 70;
       b.group_m = pick_group_m(b, cb, 1, 1); b.tm_T = b.tm_nb = 0;
       launch_cfg(cb, b, 1, s);
       UG_CHECK(hipGetLastError());
       return;
     }
+  }
+  if (planned && !(p.tune_knobs & 16384) && split == 1 && (p.tune_cfg_p1 - 1) < 0 && !(p.flags & UG_F_GEGLU)) {
+    // Round 4: every halo-stageable 3x3 convolution goes to the halo kernel (kernels/conv_halo.hip) - of its tiles the one whose tile count fills
+    // the 256 CUs best.  tools/ab_halo.py, profiles/r04_conv_halo.txt: 0.81 - 0.92 x the im2col time on levels 1 / 2 of the UNet, 0.72 - 0.95 x on the
+    // VAE decoder; the 256 x 160 tile (level 0: 320 columns) measures 1.02 - 1.08 x and stays on the row-split im2col path above unless knob 32768
+    // forces it.  Bit-identical outputs (same products, same K order).  Knob 16384 = off (A/B).
+    int best = -1; double bfill = 0.0;
+    for (int c = 70; c <= 73; ++c) {
+      const int bm = c <= 71 ? 256 : 192, bn = (c == 70 || c == 73) ? 160 : 128;
+      if (!conv_halo_supported(p, batch, bm, bn)) continue;
+      const long tiles = (long)(p.M / bm) * cdiv(p.N, bn);
+      const double useful = (double)p.N / (cdiv(p.N, bn) * bn);
+      const double fill = (double)tiles / (cdiv(tiles, 256) * 256.0) * useful * (bm == 256 ? 1.0 : 0.97);
+      if (fill > bfill) { bfill = fill; best = c; }
+    }
+    if (best >= 0 && (best != 70 || (p.tune_knobs & 32768))) cfg = best;
   }
   if (split > 1) UG_REQUIRE(p.partial != nullptr, "split-K needs a partial buffer");
   p.group_m = pick_group_m(p, cfg, batch, split);

@@ -1,0 +1,219 @@
+// Device helpers shared by the GEMM kernels (kernels/gemm.hip) and the halo-staged 3x3 convolution (kernels/conv_halo.hip):
+// activation functions, the LDS chunk swizzle, the tile walk and the per-tile epilogue.
+#pragma once
+#include "../common.h"
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7, far below the fp16 output spacing): ~12 VALU ops + one
+// exp instead of libm's erff - the GEGLU epilogue evaluates it 8x per output row per lane.
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float y = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+  const float r = 1.0f - y * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// GEGLU on two (value, gate) pairs in packed fp32 (v_pk_fma/mul/add_f32 issue two lanes' worth per instruction):
+//   h * g * Phi(g),  Phi(g) = 1/2 + sign(g) (1/2 - erfc(|g|/sqrt2)/2),  erfc by the same Abramowitz-Stegun 7.1.26 form as
+// erf_as (coefficients pre-halved, argument scaling folded in).  Per pair of outputs: 2 rcp + 2 exp2 + ~16 VALU instead of
+// ~50 for the scalar form - in the K = 320 projections the epilogue is as long as the K loop, so this is wall time.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 geglu2(f32x2 h, f32x2 g) {
+  const f32x2 ag = {__builtin_fabsf(g.x), __builtin_fabsf(g.y)};
+  const f32x2 u = ag * 0.23164189f + 1.0f;   // 1 + 0.3275911 |g| / sqrt(2)
+  const f32x2 t = {__builtin_amdgcn_rcpf(u.x), __builtin_amdgcn_rcpf(u.y)};
+  f32x2 y = t * 0.5307027145f - 0.7265760135f;
+  y = y * t + 0.7107068705f;
+  y = y * t - 0.142248368f;
+  y = y * t + 0.127414796f;
+  y = y * t;                                   // erfc(|g|/sqrt2) / 2 / exp(-g^2/2)
+  const f32x2 w = (g * g) * -0.72134752044f;   // -g^2/2 * log2(e)
+  const f32x2 e = {__builtin_amdgcn_exp2f(w.x), __builtin_amdgcn_exp2f(w.y)};
+  const f32x2 q = 0.5f - y * e;
+  const f32x2 phi = {0.5f + __builtin_copysignf(q.x, g.x), 0.5f + __builtin_copysignf(q.y, g.y)};
+  return h * g * phi;
+}
+
+// 16-byte-chunk swizzle of a [rows][BK] fp16 LDS tile: makes 16 consecutive rows reading the same logical
+// chunk land on 16 distinct 16-byte slots of the 256-byte bank row.
+template <int BK> __device__ __forceinline__ int swz(int row) {
+  if (BK == 64) return (row >> 1) & 7;   // 128-B rows, 2 rows per bank row
+  else return (row >> 2) & 3;            // 64-B rows, 4 rows per bank row
+}
+
+// Tile id -> (tm, tn).  group_m <= 1: row-major (all N tiles of one M tile are neighbours: the workgroups of an XCD share ONE
+// activation panel - right for im2col, whose A operand is re-read per tap, and for weights that fit the 4 MiB L2).  group_m = g > 1:
+// ids walk g M-tiles x all N tiles column by column, so the ~32 tiles an XCD works on at a time form a g x (32/g) block and touch
+// g + 32/g operand panels instead of 1 + 32 - for dense layers with weights far larger than the L2 the row-major walk re-fetched the
+// whole weight matrix once per M tile (profiles/r02_pmc_traffic_per_shape.txt: 4800x10240x1280 read 524 MB for 88 MB of operands).
+__device__ __forceinline__ void tile_coord(int tile, int ntm, int ntn, int group_m, int& tm, int& tn) {
+  if (group_m <= 1) { tm = tile / ntn; tn = tile - tm * ntn; return; }
+  const int per = group_m * ntn;
+  const int grp = tile / per, local = tile - grp * per;
+  const int first = grp * group_m;
+  const int gm = min(ntm - first, group_m);
+  tn = local / gm;
+  tm = first + (local - tn * gm);
+}
+// + the frame-fastest permutation of the M tiles for temporal convolutions (GemmP::tm_T)
+__device__ __forceinline__ void tile_coord_p(const GemmP& p, int tile, int ntm, int ntn, int& tm, int& tn) {
+  tile_coord(tile, ntm, ntn, p.group_m, tm, tn);
+  if (p.tm_T) { const int q = tm / p.tm_T; tm = (tm - q * p.tm_T) * p.tm_nb + q; }
+}
+
+template <int N> struct HVec;
+template <> struct HVec<8> { typedef f16x8 type; };
+template <> struct HVec<4> { typedef f16x4 type; };
+
+// Per-tile epilogue shared by the GEMM kernels: the lane holds WID = 4*NT contiguous columns of rows
+// m0 + wm*WTM + i*16 + (lane & 15).  Clears the accumulators for the next tile.
+template <int MT, int NT, int WTM, int WTN>
+__device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wm, int wn, int lane,
+                                              long out_off) {
+  constexpr int WID = 4 * NT;
+  constexpr int CH = (WID % 8 == 0) ? 8 : 4;   // vector width of the epilogue's loads / stores (WID = 20: 80-column wave tiles)
+  typedef typename HVec<CH>::type hvec;
+  const int l15 = lane & 15, g = lane >> 4;
+  const bool geglu = (p.flags & UG_F_GEGLU) != 0;
+  const bool of32 = (p.flags & UG_F_OUT_F32) != 0;
+  const int Nout = geglu ? p.N / 2 : p.N;
+  const int OW = geglu ? WID / 2 : WID;        // output columns of this lane
+  const int nb = n0 + wn * WTN + g * WID;      // lane holds WID contiguous columns of its rows
+  if (p.splitk > 1) {   // raw fp32 partials [split][M][N]
+    float* P = p.partial + ((long)blockIdx.y * p.M) * p.N;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * WTM + i * 16 + l15;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = nb + j * 4;
+        if (m < p.M && n + 4 <= p.N) *(f32x4*)(P + (long)m * p.N + n) = acc[i][j];
+        acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    return;
+  }
+  const int ob = geglu ? nb / 2 : nb;          // first output column of this lane
+  const bool full = (nb + WID <= p.N);
+  const bool vec = full && ((p.ldo & 7) == 0) && (!p.R1 || (p.ldr1 & 7) == 0) &&
+                   (!p.R2 || (p.ldr2 & 7) == 0) && (OW % CH == 0);
+  float bv[WID];
+#pragma unroll
+  for (int e = 0; e < WID; ++e) bv[e] = 0.f;
+  if (full) {
+    if (p.bias) {
+#pragma unroll
+      for (int e = 0; e < WID; e += CH) {
+        const hvec b = *(const hvec*)(p.bias + nb + e);
+#pragma unroll
+        for (int q = 0; q < CH; ++q) bv[e + q] += (float)b[q];
+      }
+    }
+    if (p.bias2) {
+#pragma unroll
+      for (int e = 0; e < WID; e += CH) {
+        const hvec b = *(const hvec*)(p.bias2 + nb + e);
+#pragma unroll
+        for (int q = 0; q < CH; ++q) bv[e + q] += (float)b[q];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < WID; ++e)
+      if (nb + e < p.N) {
+        if (p.bias) bv[e] += (float)p.bias[nb + e];
+        if (p.bias2) bv[e] += (float)p.bias2[nb + e];
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    int m = m0 + wm * WTM + i * 16 + l15;
+    if (p.halo_tw) { const int r = wm * WTM + i * 16 + l15; m = m0 + (r >> p.halo_lg) * p.Wo + (r & (p.halo_tw - 1)); }   // halo conv: 2-D pixel tile
+    long orow = m;
+    if (p.up_phase) {   // sub-pixel phase of a nearest-2x upsample conv: scatter to the (2y+a, 2x+b) output pixel
+      const int hw = p.Ho * p.Wo;
+      const int t = m / hw, rem = m - t * hw;
+      const int y = rem / p.Wo, x = rem - y * p.Wo;
+      const int ph = p.up_phase - 1;
+      orow = ((long)t * 2 * p.Ho + 2 * y + (ph >> 1)) * (2 * p.Wo) + 2 * x + (ph & 1);
+    }
+    float v[WID];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[j * 4 + r] = acc[i][j][r] + bv[j * 4 + r]; }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (m >= p.M) continue;
+    if (geglu) {
+      if (WID == 16) {
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const f32x2 r = geglu2((f32x2){v[e], v[e + 1]}, (f32x2){v[8 + e], v[9 + e]});
+          v[e] = r.x; v[e + 1] = r.y;
+        }
+      }
+    }
+    if (vec) {
+#pragma unroll
+      for (int e = 0; e < OW; e += CH) {
+        float o[CH];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) o[q] = p.c0 * v[e + q];
+        if (p.R1) {
+          if (p.flags & UG_F_R1_F32) {
+            const float* R = (const float*)p.R1 + (long)m * p.ldr1 + ob + e;
+#pragma unroll
+            for (int q = 0; q < CH; q += 4) { const f32x4 r = *(const f32x4*)(R + q); o[q] += p.c1 * r[0]; o[q + 1] += p.c1 * r[1]; o[q + 2] += p.c1 * r[2]; o[q + 3] += p.c1 * r[3]; }
+          } else {
+            const hvec r = *(const hvec*)(p.R1 + (long)m * p.ldr1 + ob + e);
+#pragma unroll
+            for (int q = 0; q < CH; ++q) o[q] += p.c1 * (float)r[q];
+          }
+        }
+        if (p.R2) {
+          const hvec r = *(const hvec*)(p.R2 + (long)m * p.ldr2 + ob + e);
+#pragma unroll
+          for (int q = 0; q < CH; ++q) o[q] += p.c2 * (float)r[q];
+        }
+        if (p.act == UG_ACT_SILU) {
+#pragma unroll
+          for (int q = 0; q < CH; ++q) o[q] = silu_f(o[q]);
+        } else if (p.act == UG_ACT_GELU) {
+#pragma unroll
+          for (int q = 0; q < CH; ++q) o[q] = gelu_f(o[q]);
+        }
+        if (of32) {
+          float* O = (float*)p.Out + out_off + orow * p.ldo + ob + e;
+#pragma unroll
+          for (int q = 0; q < CH; q += 4) *(f32x4*)(O + q) = (f32x4){o[q], o[q + 1], o[q + 2], o[q + 3]};
+        } else {
+          hvec h;
+#pragma unroll
+          for (int q = 0; q < CH; ++q) h[q] = (f16)o[q];
+          *(hvec*)((f16*)p.Out + out_off + orow * p.ldo + ob + e) = h;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < OW; ++e) {
+        const int n = ob + e;
+        if (n < Nout) {
+          float o = p.c0 * v[e];
+          if (p.R1) o += p.c1 * ((p.flags & UG_F_R1_F32) ? ((const float*)p.R1)[(long)m * p.ldr1 + n] : (float)p.R1[(long)m * p.ldr1 + n]);
+          if (p.R2) o += p.c2 * (float)p.R2[(long)m * p.ldr2 + n];
+          if (p.act == UG_ACT_SILU) o = silu_f(o);
+          else if (p.act == UG_ACT_GELU) o = gelu_f(o);
+          if (of32) ((float*)p.Out)[out_off + orow * p.ldo + n] = o;
+          else ((f16*)p.Out)[out_off + orow * p.ldo + n] = (f16)o;
+        }
+      }
+    }
+  }
+}
+

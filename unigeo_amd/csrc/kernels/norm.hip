@@ -312,50 +312,76 @@ __device__ __forceinline__ float gn_block_sum(float v, float* red) {
   return t;
 }
 
-template <int NT, int VMAX>
+// MODE 0: self-contained (statistics of the workgroup's own slab).  MODE 1 / 2 (round 4): the pooled (temporal) GroupNorm of the low-resolution
+// levels as TWO launches of per-frame slabs instead of stats / finalize / apply: MODE 1 writes (mean, sum of squared deviations) of slab
+// (group, frame) to p.ws; MODE 2 re-reads its slab (L2 / Infinity-Cache resident: <= 12 MB tensors), combines the T frame partials of its
+// group (Chan's formula in fp64, fixed order, the same in every workgroup) while the loads are in flight, and applies.
+template <int NT, int VMAX, int MODE>
 __global__ __launch_bounds__(NT) void gn_slab(const GroupNormP p) {
   typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
   __shared__ float red[NT / 64];
   const int C = p.C0 + p.C1, cpg = C / p.G, vpg = cpg / 4;
   const int g = blockIdx.x, tid = threadIdx.x;
-  const long row0 = p.temporal ? 0 : (long)blockIdx.y * p.HW;
-  const int R = p.temporal ? p.T * p.HW : p.HW;
+  const bool pooled = MODE == 0 && p.temporal;
+  const long row0 = pooled ? 0 : (long)blockIdx.y * p.HW;
+  const int R = pooled ? p.T * p.HW : p.HW;
   const int rpi = NT / vpg;
   const int rsub = tid / vpg, v = tid - rsub * vpg;
   const bool act = rsub < rpi;
   const int c = g * cpg + v * 4;
-  // buffer addressing: per-lane byte offset once, the row step as a scalar offset, rows >= R (and idle lanes) past num_records -> zeros / dropped
+  // buffer addressing: rows >= R (and idle lanes) land past num_records -> loads return zeros, stores are dropped.  The row step is added to
+  // the VECTOR offset: the range check covers voffset + the instruction offset, not the scalar offset operand.
   const bool s0 = g * cpg < p.C0;                          // the group lies in ONE source (C0 % cpg == 0, checked by gn_slab_plan)
   const int ld = s0 ? p.C0 : p.C1;
   const f16* base = (s0 ? p.X0 : p.X1) + row0 * ld;
   const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, R * ld * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Y + row0 * C), 0, R * C * 2, 0x00020000);
-  const int voff = act ? (rsub * ld + (s0 ? c : c - p.C0)) * 2 : 0x7fffffff;
-  const int yoff = act ? (rsub * C + c) * 2 : 0x7fffffff;
-  const int stepx = rpi * ld * 2, stepy = rpi * C * 2;
+  const unsigned OOB = 0x7fffffffu;
+  const unsigned voff = act ? (unsigned)(rsub * ld + (s0 ? c : c - p.C0)) * 2u : OOB;
+  const unsigned yoff = act ? (unsigned)(rsub * C + c) * 2u : OOB;
+  const unsigned stepx = rpi * ld * 2, stepy = rpi * C * 2;
   f16x4 x[VMAX];
 #pragma unroll
-  for (int k = 0; k < VMAX; ++k) x[k] = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rX, voff, k * stepx, 0));
-  float s = 0.f;
-#pragma unroll
   for (int k = 0; k < VMAX; ++k)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) s += (float)x[k][e];
+    x[k] = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rX, act ? (int)(voff + k * stepx) : (int)OOB, 0, 0));
+  float mean, rstd;
   const double n = (double)R * cpg;
-  const float mean = (float)((double)gn_block_sum<NT>(s, red) / n);
-  // keep the slab PACKED between the passes (the compiler would otherwise hold the fp32 images: twice the registers)
+  if (MODE == 2) {
+    // pooled statistics of group g from the T per-frame (mean, M2) partials; uniform addresses, every thread the same arithmetic
+    const float2* part = (const float2*)p.ws + g;
+    double msum = 0.0;
+    for (int t = 0; t < p.T; ++t) msum += (double)part[(long)t * p.G].x;
+    const double pm = msum / p.T;
+    double m2 = 0.0;
+    for (int t = 0; t < p.T; ++t) { const float2 v = part[(long)t * p.G]; const double d = (double)v.x - pm; m2 += (double)v.y + n * d * d; }
+    mean = (float)pm;
+    rstd = (float)(1.0 / sqrt(m2 / (n * p.T) + (double)p.eps));
+  } else {
+    float s = 0.f;
 #pragma unroll
-  for (int k = 0; k < VMAX; ++k) asm volatile("" : "+v"(x[k]));
-  float q = 0.f;
+    for (int k = 0; k < VMAX; ++k)
 #pragma unroll
-  for (int k = 0; k < VMAX; ++k)
-    if (act && rsub + k * rpi < R) {
+      for (int e = 0; e < 4; ++e) s += (float)x[k][e];
+    mean = (float)((double)gn_block_sum<NT>(s, red) / n);
+    // keep the slab PACKED between the passes (the compiler would otherwise hold the fp32 images: twice the registers)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float d = (float)x[k][e] - mean; q += d * d; }
+    for (int k = 0; k < VMAX; ++k) asm volatile("" : "+v"(x[k]));
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < VMAX; ++k)
+      if (act && rsub + k * rpi < R) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = (float)x[k][e] - mean; q += d * d; }
+      }
+    const float qs = gn_block_sum<NT>(q, red);
+    if (MODE == 1) {
+      if (tid == 0) ((float2*)p.ws)[(long)blockIdx.y * p.G + g] = make_float2(mean, qs);
+      return;
     }
-  const float rstd = (float)(1.0 / sqrt((double)gn_block_sum<NT>(q, red) / n + (double)p.eps));
+    rstd = (float)(1.0 / sqrt((double)qs / n + (double)p.eps));
 #pragma unroll
-  for (int k = 0; k < VMAX; ++k) asm volatile("" : "+v"(x[k]));
+    for (int k = 0; k < VMAX; ++k) asm volatile("" : "+v"(x[k]));
+  }
   const f16x4 ga = *(const f16x4*)(p.gamma + (act ? c : 0)), be = *(const f16x4*)(p.beta + (act ? c : 0));
   float a[4], b[4];
 #pragma unroll
@@ -369,17 +395,34 @@ __global__ __launch_bounds__(NT) void gn_slab(const GroupNormP p) {
       if (p.silu) f = silu_f(f);
       y[e] = (f16)f;
     }
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, y), rY, yoff, k * stepy, 0);   // rows >= R: out of range, dropped
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, y), rY, act ? (int)(yoff + k * stepy) : (int)OOB, 0, 0);   // rows >= R: dropped
+  }
+}
+
+template <int MODE>
+static void gn_slab_launch(const GroupNormP& p, int snt, int svmax, dim3 grid, hipStream_t s) {
+  if (snt == 256) {
+    if (svmax <= 4) hipLaunchKernelGGL((gn_slab<256, 4, MODE>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gn_slab<256, 8, MODE>), grid, dim3(256), 0, s, p);
+  } else {
+    switch (svmax) {
+      case 4: hipLaunchKernelGGL((gn_slab<1024, 4, MODE>), grid, dim3(1024), 0, s, p); break;
+      case 8: hipLaunchKernelGGL((gn_slab<1024, 8, MODE>), grid, dim3(1024), 0, s, p); break;
+      case 16: hipLaunchKernelGGL((gn_slab<1024, 16, MODE>), grid, dim3(1024), 0, s, p); break;
+      case 32: hipLaunchKernelGGL((gn_slab<1024, 32, MODE>), grid, dim3(1024), 0, s, p); break;
+      default: hipLaunchKernelGGL((gn_slab<1024, 48, MODE>), grid, dim3(1024), 0, s, p); break;
+    }
   }
 }
 
 // slab-form plan: threads per workgroup and register vectors per thread, 0 = does not fit
-static inline int gn_slab_plan(const GroupNormP& p, int& vmax) {
+static inline int gn_slab_plan(const GroupNormP& p, int& vmax, bool per_frame = false) {
   const int C = p.C0 + p.C1, cpg = C / p.G;
+  const bool pooled = p.temporal && !per_frame;
   if (cpg % 4 || p.C0 % cpg || !p.gamma || !p.beta || cpg / 4 > 64) return 0;
-  if ((p.temporal ? (long)p.T * p.HW : (long)p.HW) * C * 2 >= (1L << 31)) return 0;
+  if ((pooled ? (long)p.T * p.HW : (long)p.HW) * C * 2 >= (1L << 31)) return 0;
   const int vpg = cpg / 4;
-  const long R = p.temporal ? (long)p.T * p.HW : p.HW;
+  const long R = pooled ? (long)p.T * p.HW : p.HW;
   for (int nt : {256, 1024}) {
     const long k = (R + nt / vpg - 1) / (nt / vpg);
     const int cap = nt == 256 ? 8 : 48;
@@ -596,6 +639,8 @@ size_t groupnorm_ws_floats(int T, int HW, int C, int G) {
 
 // Launch scheme (p.mode 0 = pick, 1 / 2 / 3 / 4 force; tools/bench_groupnorm.py, profiles/r01_groupnorm_variants.txt):
 //   4: gn_slab, one workgroup per (group, frame) with the slab in registers (round 3; replaces 2 wherever it fits)
+//   6: pooled statistics from per-frame slabs, two launches (round 4).  Round 4 also re-measured gn_apply combining the chunk partials itself (no
+//      gn_finalize launch, first loads issued before the combine): 41.2 vs 40.3 us isolated, +3 us on the one-frame StableNormal tensors, +-0 in the clip - removed.
 //   1: gn_stats / gn_finalize / gn_apply   2: gn_small, one workgroup per (group, frame) - wins on the low-resolution levels,
 //      loses when a row contributes < 64 B to a group and there are many rows (T25 x HW768 x C640: 47 vs 28 us).
 // Also measured and removed: apply with an in-block finalize (2 launches; +3.5 us of serial latency per workgroup, no
@@ -612,35 +657,31 @@ void launch_groupnorm(const GroupNormP& p, hipStream_t s) {
   int mode = p.mode;
   int fch = 0, frpc = 0;
   const bool fused_ok = gn_fused_plan(p, fch, frpc);
-  int svmax = 0;
+  int svmax = 0, tvmax = 0;
   const int snt = gn_slab_plan(p, svmax);
+  const int tnt = p.temporal ? gn_slab_plan(p, tvmax, true) : 0;   // per-frame slabs of the pooled variant (mode 6)
   if (mode == 0) {
     // tools/bench_groupnorm.py, profiles/r03_groupnorm_slab.txt: the register-slab form wins wherever gn_small did (T25 x HW192 x C1280 12.2 vs
     // 16.5 us, x C2560 19.7 vs 27.4, T1 x HW256 x C1280 5.9 vs 10.9) and up to 64 K elements per slab when a row gives a group >= 64 B and
-    // the grid fills the chip (T25 x HW768 x C1280 38.7 vs 41.4); pooled (temporal) slabs have only G workgroups: 3 launches stay faster
+    // the grid fills the chip (T25 x HW768 x C1280 38.7 vs 41.4); pooled (temporal) slabs have only G workgroups: two launches of per-frame
+    // slabs on the two low-resolution levels (mode 6; profiles/r04_groupnorm_modes.txt: 22.4 vs 23.8 us, 15.2 vs 16.0; the 768-row level loses 53 vs 30)
     const bool narrow_ok = p.HW <= 256 || cpg >= 32;
-    static const bool noslab = getenv("UG_GN_NOSLAB") != nullptr;   // A/B aid
+    static const bool noslab = getenv("UG_GN_NOSLAB") != nullptr;   // A/B aids
+    static const bool not2 = getenv("UG_GN_NOT2") != nullptr;
     if (small_ok && slab <= 16384 && narrow_ok) mode = (snt && !noslab) ? 4 : 2;
     else if (!p.temporal && snt && svmax <= 16 && narrow_ok && p.G * p.T >= 256 && !noslab) mode = 4;
+    else if (p.temporal && tnt && tvmax <= 16 && p.HW <= 256 && p.G * p.T >= 256 && !not2) mode = 6;
     else mode = fused_ok ? 3 : 1;
   }
   if (mode == 4 && !snt) mode = p.temporal ? 1 : 2;
   if (mode == 2 && !small_ok) mode = 1;
   if (mode == 3 && !fused_ok) mode = 1;
+  if (mode == 6 && !tnt) mode = 1;
   if (mode == 4) {
-    const dim3 grid(p.G, p.temporal ? 1 : p.T);
-    if (snt == 256) {
-      if (svmax <= 4) hipLaunchKernelGGL((gn_slab<256, 4>), grid, dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((gn_slab<256, 8>), grid, dim3(256), 0, s, p);
-    } else {
-      switch (svmax) {
-        case 4: hipLaunchKernelGGL((gn_slab<1024, 4>), grid, dim3(1024), 0, s, p); break;
-        case 8: hipLaunchKernelGGL((gn_slab<1024, 8>), grid, dim3(1024), 0, s, p); break;
-        case 16: hipLaunchKernelGGL((gn_slab<1024, 16>), grid, dim3(1024), 0, s, p); break;
-        case 32: hipLaunchKernelGGL((gn_slab<1024, 32>), grid, dim3(1024), 0, s, p); break;
-        default: hipLaunchKernelGGL((gn_slab<1024, 48>), grid, dim3(1024), 0, s, p); break;
-      }
-    }
+    gn_slab_launch<0>(p, snt, svmax, dim3(p.G, p.temporal ? 1 : p.T), s);
+  } else if (mode == 6) {
+    gn_slab_launch<1>(p, tnt, tvmax, dim3(p.G, p.T), s);
+    gn_slab_launch<2>(p, tnt, tvmax, dim3(p.G, p.T), s);
   } else if (mode == 3) {
     const GnGeom gg = gn_geom(C);
     const size_t lds = std::max((size_t)gg.rpi * C * 2 * sizeof(float), (size_t)p.G * 2 * sizeof(float));

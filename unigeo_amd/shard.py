@@ -50,3 +50,23 @@ def run_sharded(n_clips, rank, world, dist, run_clip, make_dummy):
             if i < n_clips:
                 results[i] = got[src]
     return results
+
+
+def pin_rank_to_cores(local_rank: int, world: int):
+    """One process per GPU, and every process enqueues ~25 k kernel launches per clip from one host thread: with 8 ranks on one host the
+    launch threads must not migrate onto each other's cores.  Gives rank ``local_rank`` the ``local_rank``-th contiguous slice of the cores
+    this process is allowed to use (``os.sched_getaffinity``), at least one core; a single rank keeps what it has.  Returns the core list
+    (for the bench line), or None where the platform has no affinity call.  eval.py of the reference is single-process
+    (``/root/reference/eval.py:33-56``): there is nothing to mirror, this is launch-side hygiene of the sharded run."""
+    import os
+    if world <= 1 or not hasattr(os, "sched_getaffinity"):
+        return None
+    cores = sorted(os.sched_getaffinity(0))
+    per = max(1, len(cores) // world)
+    lo = (local_rank * per) % len(cores)
+    mine = cores[lo:lo + per] or cores[:1]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    return mine
