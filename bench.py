@@ -104,6 +104,7 @@ def calibration_probe(eng):
         eng.bench_gemm(8192, 8192, 8192, iters=3)
         ms, tf, cfg, _ = eng.bench_gemm(8192, 8192, 8192, iters=10)
         out["gemm_8192_tflops"] = round(float(tf), 1)
+        out["mfma_regs_only_tflops"] = round(float(eng.bench_mfma_peak()), 1)   # matrix pipes alone, operands in registers: the achievable MFMA ceiling of THIS box
         us = eng.bench_groupnorm(128, 0, 16, 196608, 0, 1, iters=10)
         out["groupnorm_stream_gbps"] = round(float(16 * 196608 * 128 * 2 * 3 / (us * 1e-6) / 1e9), 1)
     except Exception as e:   # a probe must never cost the headline
@@ -430,14 +431,18 @@ def main():
                                "note": "algorithmic FLOPs (SURVEY 8d): a nearest-2x upsample + 3x3 conv is credited its 9-tap FLOPs although the "
                                        "sub-pixel kernel (gemm_conv_up2x2) executes 4 taps - its apparent > 1 PFLOP/s rates in per-shape tables are not MFMA rates",
                                "algorithmic_bytes_per_launch": round(sum(v.get("bytes", 0) for v in gem.values()) / max(g_calls, 1))}
+            mp = res["calibration"].get("mfma_regs_only_tflops")
+            if mp:   # also against a MEASURED MFMA micro-benchmark peak (kernels/probe.hip: operands in registers, nothing but matrix instructions)
+                res["roofline"]["peak_measured_mfma_only"] = mp
+                res["roofline"]["frac_of_measured_peak"] = round(ach / mp, 4)
             # HBM traffic of the same kernel family: rocprofv3 PMC passes collected by the committed script tools/pmc_traffic.sh
             # (FETCH_SIZE and WRITE_SIZE in separate passes, counters only) -> profiles/r03_pmc_traffic_gemm.json, which
             # also carries the algorithmic bytes of ITS OWN step mix; the file is cited by hash
             try:
                 import hashlib
-                pf = os.path.join(ROOT, "profiles", "r03_pmc_traffic_gemm.json")
+                pf = os.path.join(ROOT, "profiles", "r04_pmc_traffic_gemm.json")
                 if not os.path.exists(pf):
-                    pf = os.path.join(ROOT, "profiles", "r02_pmc_traffic_gemm.json")
+                    pf = os.path.join(ROOT, "profiles", "r03_pmc_traffic_gemm.json")
                 raw = open(pf, "rb").read()
                 pm = json.loads(raw)
                 res["roofline"]["traffic"] = round(pm["hbm_bytes_per_launch"])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """In-process A/B of engine switches on the full-size clip (25 x 384 x 512, 25 steps): box-to-box spread is +-4 %, so variants are
-only ever compared inside one process.  usage: ab_clip.py ff_fused|ff_ln|conv_split|fp8|vae32|flash|flash_xcd|group|snsmall|insitu|gnfused|lvl3|lnqkv|xstep|ring4|ffpipe|ffxt|lanes|lanes2|lanes4 [repeats]"""
+only ever compared inside one process.  usage: ab_clip.py ff_fused|ff_ln|conv_split|fp8|vae32|flash|flashlazy|flashpp|group|snsmall|insitu|lvl3|ffxt|halo|halo_l0|lanes|lanes2|lanes4 [repeats]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,9 +15,12 @@ eng = pipe.engine
 clip = synthetic_clip(T, H, W)
 nl, na = make_noise(T, H, W, 0)
 eng.set_inputs(DepthCrafter.prepare_input(None, clip), nl, na, np.stack(clip["intrinsics"], 0))
-setter = {"conv_split": lambda on: eng.tune_force(-100 - (0 if on else 1024), 0), "group": lambda on: eng.tune_force(-100 - (0 if on else 32), 0), "flash": lambda on: eng.lib.ug_tune_flash(7 if on else 3), "flashlazy": lambda on: eng.lib.ug_tune_flash(23 if on else 7), "flashpipe": lambda on: eng.lib.ug_tune_flash(39 if on else 23), "flash_xcd": lambda on: eng.lib.ug_tune_flash(3 if on else 1), "flash5": lambda on: eng.lib.ug_tune_flash(5 if on else 7), "flash6": lambda on: eng.lib.ug_tune_flash(6 if on else 7), "ff_fused": eng.set_ff_fused, "ff_ln": lambda on: eng.set_ff_fused(True, prenorm=on), "lnqkv": lambda on: eng.lib.ug_set_ff_fused(eng.ctx, 7 if on else 3), "fp8": eng.set_fp8_linears, "vae32": eng.set_vae_encode_fp32,
-          "snsmall": lambda on: eng.tune_force(-100 - (0 if on else 8192), 0), "insitu": lambda on: eng.tune_force(-100 - (0 if on else 4096), 0), "gnfused": eng.set_gn_fused, "lvl3": lambda on: eng.tune_force(-100 - (0 if on else 2048), 0), "ffpipe": lambda on: eng.lib.ug_tune_ff(1 if on else 0), "ffxt": lambda on: eng.lib.ug_tune_ff(2 if on else 0),
-          "xstep": lambda on: eng.tune_force(-100 - (131072 if on else 0), 0), "ring4": lambda on: eng.tune_force(-100 - (65536 if on else 0), 0),
+setter = {"conv_split": lambda on: eng.tune_force(-100 - (0 if on else 1024), 0), "group": lambda on: eng.tune_force(-100 - (0 if on else 32), 0),
+          "flash": lambda on: eng.tune_flash(7 if on else 3), "flashlazy": lambda on: eng.tune_flash(23 if on else 7), "flashpp": lambda on: eng.tune_flash(87 if on else 23),
+          "snsmall": lambda on: eng.tune_force(-100 - (0 if on else 8192), 0), "insitu": lambda on: eng.tune_force(-100 - (0 if on else 4096), 0),
+          "lvl3": lambda on: eng.tune_force(-100 - (0 if on else 2048), 0), "ffxt": lambda on: eng.tune_ff(0 if on else 1),
+          "halo": lambda on: eng.tune_force(-100 - (0 if on else 16384), 0), "halo_l0": lambda on: eng.tune_force(-100 - (32768 if on else 0), 0),
+          "ff_fused": lambda on: eng.set_ff_fused(on, prenorm=on), "ff_ln": lambda on: eng.set_ff_fused(True, prenorm=on), "fp8": eng.set_fp8_linears, "vae32": eng.set_vae_encode_fp32,
           "lanes": lambda on: eng.set_concurrency(3 if on else 1), "lanes2": lambda on: eng.set_concurrency(2 if on else 1), "lanes4": lambda on: eng.set_concurrency(4 if on else 1)}[what]
 eng.run(25, 8)
 for rnd in range(reps):

@@ -18,12 +18,12 @@ EXPORTS = [
     "ug_unet_config_default", "ug_vae_config_default", "ug_clip_config_default",
     "ug_create", "ug_destroy", "ug_last_error", "ug_workspace_peak",
     "ug_load_tensor", "ug_bind_unet", "ug_bind_vae", "ug_bind_clip",
-    "ug_dc_set_inputs", "ug_dc_run", "ug_dc_run_windows", "ug_dc_get_outputs", "ug_dc_device_ptrs", "ug_dc_set_trace", "ug_set_vae_encode_fp32", "ug_set_gn_fused", "ug_set_concurrency", "ug_set_fp8_linears", "ug_op_linear_mx8", "ug_set_ff_fused", "ug_op_ff", "ug_op_ln_ff", "ug_op_ln_linear", "ug_bench_ff", "ug_bench_flash", "ug_tune_flash", "ug_tune_ff",
+    "ug_dc_set_inputs", "ug_dc_run", "ug_dc_run_windows", "ug_dc_get_outputs", "ug_dc_device_ptrs", "ug_dc_set_trace", "ug_set_vae_encode_fp32", "ug_set_concurrency", "ug_set_fp8_linears", "ug_op_linear_mx8", "ug_set_ff_fused", "ug_op_ff", "ug_op_ln_ff", "ug_bench_ff", "ug_bench_flash", "ug_tune_flash", "ug_tune_ff",
     "ug_eval_depth", "ug_eval_normal", "ug_clip_embed", "ug_vae_encode", "ug_vae_decode", "ug_unet_forward", "ug_normals_from_depth",
     "ug_op_linear", "ug_op_conv", "ug_op_groupnorm", "ug_op_layernorm", "ug_op_flash_attn",
     "ug_op_temporal_attn", "ug_op_attention_generic", "ug_op_flash_attn_dh", "ug_op_euler_step",
     "ug_bind_stablenormal", "ug_sn_run", "ug_sn_unet_forward", "ug_sn_dino", "ug_sn_vae_decode", "ug_sn_vae_encode", "ug_resize_bilinear",
-    "ug_profile_begin", "ug_profile_begin_shapes", "ug_profile_end", "ug_bench_gemm", "ug_bench_groupnorm", "ug_tune_force",
+    "ug_profile_begin", "ug_profile_begin_shapes", "ug_profile_end", "ug_bench_gemm", "ug_bench_groupnorm", "ug_bench_mfma_peak", "ug_tune_force",
 ]
 
 
@@ -84,15 +84,13 @@ def load_library():
     try:
         lib.ug_set_fp8_linears.argtypes = [vp, ip]
         lib.ug_set_concurrency.argtypes = [vp, ip]
-        lib.ug_set_gn_fused.argtypes = [vp, ip]
         lib.ug_set_ff_fused.argtypes = [vp, ip]
         lib.ug_bench_ff.argtypes = [vp, ip, ip, ip, ip, vp]
         lib.ug_bench_flash.argtypes = [vp, ip, ip, ip, ip, ip, vp]
-        lib.ug_tune_flash.argtypes = [ip]
-        lib.ug_tune_ff.argtypes = [ip]
+        lib.ug_tune_flash.argtypes = [vp, ip]
+        lib.ug_tune_ff.argtypes = [vp, ip]
         lib.ug_op_ff.argtypes = [vp, vp, ip, ip, vp, vp, vp, vp, vp, C.c_float, C.c_float, ip, vp]
         lib.ug_op_ln_ff.argtypes = [vp, vp, ip, ip, vp, vp, C.c_float, vp, ip, vp, vp, vp, vp, C.c_float, C.c_float, ip, vp]
-        lib.ug_op_ln_linear.argtypes = [vp, vp, ip, ip, vp, vp, C.c_float, vp, ip, vp, ip, ip, vp, vp]
         lib.ug_op_linear_mx8.argtypes = [vp, vp, ip, ip, vp, ip, vp, ip, vp, vp, vp]
     except AttributeError:
         if not os.environ.get("UG_LIB_PATH"):      # only an explicitly selected OLDER build (tools/ab A/B runs) may lack these
@@ -299,10 +297,6 @@ class Engine:
         """Independent chunks (VAE encode / decode chunks, CLIP tower) in flight on separate HIP streams; 1 = serial.  Bit-identical outputs."""
         self._ck(self.lib.ug_set_concurrency(self.ctx, int(lanes)))
 
-    def set_gn_fused(self, on=True):
-        """One-launch GroupNorm (rows kept in registers across the statistics hand-off) for the UNet-sized tensors; False = three launches."""
-        self._ck(self.lib.ug_set_gn_fused(self.ctx, int(bool(on))))
-
     def set_vae_encode_fp32(self, on=True):
         """True (default) = the reference's float32 VAE encoder (force_upcast); False = fp16 storage like the decoder."""
         self._ck(self.lib.ug_set_vae_encode_fp32(self.ctx, int(bool(on))))
@@ -317,12 +311,17 @@ class Engine:
         self._ck(self.lib.ug_bench_ff(self.ctx, int(M), int(C), int(bool(fused)), int(iters), _ptr(out)))
         return float(out[0])
 
-    def set_ff_fused(self, on=True, prenorm=True, ln_qkv=None):
-        """Fused GEGLU feed-forward kernel of the narrow transformer blocks (on), its LayerNorm inside the kernel (prenorm) and the fused
-        LayerNorm -> Q|K|V projection kernel (ln_qkv; off unless asked for); A/B aid."""
-        if ln_qkv is None:
-            ln_qkv = False          # measured slower than LayerNorm launch + GEMM (tools/bench_lnqkv.py); opt-in
-        self._ck(self.lib.ug_set_ff_fused(self.ctx, (1 if on else 0) | (2 if on and prenorm else 0) | (4 if ln_qkv else 0)))
+    def set_ff_fused(self, on=True, prenorm=True):
+        """Fused GEGLU feed-forward kernel of the narrow transformer blocks (on) and its LayerNorm inside the kernel (prenorm); A/B aid."""
+        self._ck(self.lib.ug_set_ff_fused(self.ctx, (1 if on else 0) | (2 if on and prenorm else 0)))
+
+    def tune_ff(self, variant=0):
+        """Per-context A/B aid: fused feed-forward kernel form, 0 = cross-tile prefetch (default), 1 = without it."""
+        self._ck(self.lib.ug_tune_ff(self.ctx, int(variant)))
+
+    def tune_flash(self, variant=-1):
+        """Per-context test aid: flash-attention variant mask of this context's launches (-1 = default 23)."""
+        self._ck(self.lib.ug_tune_flash(self.ctx, int(variant)))
 
     def op_ln_ff(self, X, gamma, beta, W1, b1, W2, b2, addvec=None, rows_per_vec=1, eps=1e-5, c0=1.0, c1=1.0, mode=2):
         X = _f32(X); M, Cc = X.shape
@@ -331,15 +330,6 @@ class Engine:
         self._ck(self.lib.ug_op_ln_ff(self.ctx, _ptr(X), M, Cc, _ptr(_f32(gamma)), _ptr(_f32(beta)), float(eps), _ptr(av), int(rows_per_vec),
                                       _ptr(_f32(W1)), _ptr(_f32(b1)), _ptr(_f32(W2)), _ptr(_f32(b2)), float(c0), float(c1), int(mode), _ptr(out)))
         return out
-
-    def op_ln_linear(self, X, gamma, beta, W, bias=None, eps=1e-5, fused=True, iters=0):
-        """LayerNorm(X) @ W.T (+ bias); fused = the X-resident kernel, else LayerNorm launch + GEMM.  iters > 0: returns (out, microseconds per call)."""
-        X = _f32(X); M, Cc = X.shape; Wf = _f32(W); N = Wf.shape[0]
-        out = np.empty((M, N), np.float32); us = np.zeros(1, np.float32)
-        b = None if bias is None else _f32(bias)
-        self._ck(self.lib.ug_op_ln_linear(self.ctx, _ptr(X), M, Cc, _ptr(_f32(gamma)), _ptr(_f32(beta)), float(eps), _ptr(Wf), N, _ptr(b), int(bool(fused)), int(iters),
-                                          _ptr(out), _ptr(us)))
-        return (out, float(us[0])) if iters > 0 else out
 
     def op_ff(self, X, W1, b1, W2, b2, R1=None, c0=1.0, c1=1.0, fused=True):
         X = _f32(X); M, Cc = X.shape
@@ -512,6 +502,13 @@ class Engine:
                                         cv.get("ups", 1), cfg, split, iters, _ptr(out)))
         Mr, Kr = float(out[3]), float(out[4])
         return float(out[0]), 2.0 * Mr * N * Kr / (out[0] * 1e-3) / 1e12, int(out[1]), int(out[2])
+
+    def bench_mfma_peak(self, iters=20000):
+        """Calibration: chip-wide fp16 MFMA TFLOP/s with operands in registers (kernels/probe.hip)."""
+        out = np.zeros(1, np.float32)
+        self.lib.ug_bench_mfma_peak.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self._ck(self.lib.ug_bench_mfma_peak(self.ctx, int(iters), _ptr(out)))
+        return float(out[0])
 
     def tune_force(self, cfg=-1, split=-1):
         """Test / A-B aid, per context: force a GEMM tile config + split-K factor ((-1, -1) = planner); cfg = -100 - mask sets the knob mask."""

@@ -1,4 +1,4 @@
-// extern "C" surface of libunigeo_hip.so (declared in include/unigeo_hip.h).
+// extern "C" surface of libunigeo_hip.so (declared in include/unigeo_hip.h - the drop-in boundary - and include/unigeo_hip_test.h - test / tuning entry points).
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/unigeo_hip.h"
+#include "../../include/unigeo_hip_test.h"
 #include "engine.h"
 
 using namespace ug;
@@ -126,12 +127,12 @@ int ug_dc_run_windows(ug_ctx* x, int steps, int chunk, int with_normals, int win
 }
 int ug_set_ff_fused(ug_ctx* x, int on) {
   if (!x) return -1;
-  x->c.ff_fused = on & 7;   // bit 0: fused feed-forward kernel, bit 1: its pre-LayerNorm inside the kernel, bit 2: fused LayerNorm -> Q|K|V projection
+  x->c.ff_fused = on & 3; x->c.lane_need.clear();   // (a feature toggle changes the transient memory a lane task needs)   // bit 0: fused feed-forward kernel, bit 1: its pre-LayerNorm inside the kernel, bit 2: fused LayerNorm -> Q|K|V projection
   return 0;
 }
 int ug_set_fp8_linears(ug_ctx* x, int on) {
   if (!x) return -1;
-  x->c.fp8_linears = on ? 1 : 0;
+  x->c.fp8_linears = on ? 1 : 0; x->c.lane_need.clear();
   return 0;
 }
 int ug_set_concurrency(ug_ctx* x, int lanes) {
@@ -139,14 +140,9 @@ int ug_set_concurrency(ug_ctx* x, int lanes) {
   x->c.concurrency = std::max(1, std::min(lanes, 8));
   return 0;
 }
-int ug_set_gn_fused(ug_ctx* x, int on) {
-  if (!x) return -1;
-  x->c.gn_fused_on = on ? 1 : 0;
-  return 0;
-}
 int ug_set_vae_encode_fp32(ug_ctx* x, int on) {
   if (!x) return -1;
-  x->c.vae_encode_fp32 = on ? 1 : 0;
+  x->c.vae_encode_fp32 = on ? 1 : 0; x->c.lane_need.clear();
   return 0;
 }
 int ug_dc_set_trace(ug_ctx* x, float* host_latents, int steps) {
@@ -513,7 +509,7 @@ int ug_op_ln_ff(ug_ctx* x, const float* X, int M, int C, const float* gamma, con
     f16* dg = up16(c, gamma, C); f16* dbt = up16(c, beta, C); f16* dav = addvec ? up16(c, addvec, (long)nvec * C) : nullptr;
     f16* dO = c.ws.get<f16>((long)M * C);
     FFusedP p; memset(&p, 0, sizeof(p));
-    p.W1 = dW1; p.b1 = db1; p.W2 = dW2; p.b2 = db2; p.c0 = c0; p.c1 = c1; p.Out = dO; p.M = M; p.C = C; p.zero = c.zero;
+    p.W1 = dW1; p.b1 = db1; p.W2 = dW2; p.b2 = db2; p.c0 = c0; p.c1 = c1; p.Out = dO; p.M = M; p.C = C; p.zero = c.zero; p.variant = c.ff_variant;
     if (mode == 2) {
       p.X = dX; p.R1 = dX; p.ln_g = dg; p.ln_b = dbt; p.ln_eps = eps; p.addvec = dav; p.rows_per_vec = rows_per_vec;
       launch_ff_fused(p, c.stream);
@@ -559,7 +555,7 @@ int ug_op_ff(ug_ctx* x, const float* X, int M, int C, const float* W1, const flo
     f16* dO = c.ws.get<f16>((long)M * C);
     if (fused) {
       FFusedP p; memset(&p, 0, sizeof(p));
-      p.X = dX; p.W1 = dW1; p.b1 = db1; p.W2 = dW2; p.b2 = db2; p.R1 = dR; p.c0 = c0; p.c1 = c1; p.Out = dO; p.M = M; p.C = C; p.zero = c.zero;
+      p.X = dX; p.W1 = dW1; p.b1 = db1; p.W2 = dW2; p.b2 = db2; p.R1 = dR; p.c0 = c0; p.c1 = c1; p.Out = dO; p.M = M; p.C = C; p.zero = c.zero; p.variant = c.ff_variant;
       launch_ff_fused(p, c.stream);
     } else {
       f16* mid = c.ws.get<f16>((long)M * I);
@@ -573,45 +569,6 @@ int ug_op_ff(ug_ctx* x, const float* X, int M, int C, const float* W1, const flo
       gemm_apply_tune(g2, c.tune); launch_gemm(g2, 1, c.stream);
     }
     down16(c, dO, out, (long)M * C);
-  });
-}
-// LayerNorm(X) . W^T (+ bias) on [M, C] -> [M, N]: fused = 1 the X-resident kernel (kernels/ff_fused.hip: ln_linear_kernel), 0 = LayerNorm launch + GEMM
-int ug_op_ln_linear(ug_ctx* x, const float* X, int M, int C, const float* gamma, const float* beta, float eps, const float* W, int N, const float* bias,
-                    int fused, int iters, float* out, float* us_out) {
-  UG_TRY(x, {
-    Ctx& c = x->c; Scope sc(c);
-    f16* dX = up16(c, X, (long)M * C); f16* dW = up16(c, W, (long)N * C); f16* db = up16_opt(c, bias, N);
-    f16* dg = up16(c, gamma, C); f16* dbt = up16(c, beta, C);
-    f16* dO = c.ws.get<f16>((long)M * N); f16* t1 = c.ws.get<f16>((long)M * C);
-    auto run = [&]() {
-      if (fused) {
-        UG_REQUIRE(ln_linear_supported(C, N), "ln_linear: unsupported C / N");
-        LnLinP p; memset(&p, 0, sizeof(p));
-        p.X = dX; p.W = dW; p.bias = db; p.Out = dO; p.ldo = N; p.M = M; p.C = C; p.N = N; p.ln_g = dg; p.ln_b = dbt; p.ln_eps = eps;
-        launch_ln_linear(p, c.stream);
-      } else {
-        LayerNormP l; memset(&l, 0, sizeof(l));
-        l.X = dX; l.Y = t1; l.M = M; l.C = C; l.eps = eps; l.gamma = dg; l.beta = dbt; l.rows_per_vec = 1;
-        launch_layernorm(l, c.stream);
-        GemmP g1; memset(&g1, 0, sizeof(g1));
-        g1.A0 = t1; g1.C0 = C; g1.M = M; g1.N = N; g1.K = C; g1.W = dW; g1.ldw = C; g1.bias = db; g1.c0 = 1.f; g1.Out = dO; g1.ldo = N; g1.zero = c.zero; g1.nb_inner = 1;
-        g1.splitk = 1;
-        gemm_apply_tune(g1, c.tune); launch_gemm(g1, 1, c.stream);
-      }
-    };
-    run();
-    if (iters > 0 && us_out) {
-      run();
-      hipEvent_t e0, e1; UG_CHECK(hipEventCreate(&e0)); UG_CHECK(hipEventCreate(&e1));
-      UG_CHECK(hipEventRecord(e0, c.stream));
-      for (int i = 0; i < iters; ++i) run();
-      UG_CHECK(hipEventRecord(e1, c.stream));
-      UG_CHECK(hipEventSynchronize(e1));
-      float ms = 0.f; UG_CHECK(hipEventElapsedTime(&ms, e0, e1));
-      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-      *us_out = ms * 1000.f / iters;
-    }
-    down16(c, dO, out, (long)M * N);
   });
 }
 int ug_bench_flash(ug_ctx* x, int B, int H, int S, int variant, int iters, float* us_out) {
@@ -645,7 +602,7 @@ int ug_bench_ff(ug_ctx* x, int M, int C, int fused, int iters, float* us_out) {
     launch_scale_f16(dW1, dW1, 0.05f, (long)2 * I * C, c.stream); launch_scale_f16(dW2, dW2, 0.03f, (long)C * I, c.stream);
     auto run = [&]() {
       if (fused) {
-        FFusedP p; memset(&p, 0, sizeof(p));
+        FFusedP p; memset(&p, 0, sizeof(p)); p.variant = c.ff_variant;
         p.X = dX; p.W1 = dW1; p.b1 = db1; p.W2 = dW2; p.b2 = db2; p.R1 = dR; p.c0 = 1.f; p.c1 = 1.f; p.Out = dO; p.M = M; p.C = C; p.zero = c.zero;
         launch_ff_fused(p, c.stream);
       } else {
@@ -747,10 +704,8 @@ int ug_op_groupnorm(ug_ctx* x, const float* x0, int C0, const float* x1, int C1,
     p.gamma = up16(c, gamma, C); p.beta = up16(c, beta, C);
     f16* y = c.ws.get<f16>(M * C); p.Y = y;
     p.ws = c.ws.get<float>((long)groupnorm_ws_floats(T, HW, C, G));
-    gn_attach(c, p);
     launch_groupnorm(p, c.stream);
     down16(c, y, out, M * C);
-    gn_check(c);
   });
 }
 
@@ -766,7 +721,6 @@ int ug_bench_groupnorm(ug_ctx* x, int C0, int C1, int T, int HW, int temporal, i
     p.X0 = a0; p.X1 = a1; p.C0 = C0; p.C1 = C1; p.T = T; p.HW = HW; p.G = 32; p.eps = 1e-5f; p.temporal = temporal; p.silu = 1;
     p.gamma = gm; p.beta = bt; p.Y = c.ws.get<f16>(M * C); p.mode = mode;
     p.ws = c.ws.get<float>((long)groupnorm_ws_floats(T, HW, C, 32));
-    auto launch_groupnorm = [&](GroupNormP& q, hipStream_t st) { gn_attach(c, q); if (mode == 1 || mode == 2) q.sync = nullptr; ::launch_groupnorm(q, st); };
     for (int i = 0; i < 3; ++i) launch_groupnorm(p, c.stream);
     hipEvent_t e0, e1; UG_CHECK(hipEventCreate(&e0)); UG_CHECK(hipEventCreate(&e1));
     UG_CHECK(hipEventRecord(e0, c.stream));
@@ -802,7 +756,7 @@ int ug_op_flash_attn(ug_ctx* x, const float* qkv, int B, int H, int S, float* ou
     Ctx& c = x->c; Scope sc(c);
     const int C = H * 64; const long M = (long)B * S;
     f16* d = up16(c, qkv, M * 3 * C); f16* o = c.ws.get<f16>(M * C);
-    FlashP p; p.Q = d; p.K = d + C; p.V = d + 2 * C; p.ldq = p.ldk = p.ldv = 3 * C; p.O = o; p.ldo = C;
+    FlashP p; p.Q = d; p.K = d + C; p.V = d + 2 * C; p.ldq = p.ldk = p.ldv = 3 * C; p.O = o; p.ldo = C; p.variant = c.flash_variant;
     p.B = B; p.H = H; p.S = S; p.scale = 0.125f;
     launch_flash_attn64(p, c.stream);
     down16(c, o, out, M * C);
@@ -836,21 +790,29 @@ int ug_op_flash_attn_dh(ug_ctx* x, const float* qkv, int B, int S, int H, int d,
     Ctx& c = x->c; Scope sc(c);
     const int C = H * d; const long M = (long)B * S;
     f16* dq = up16(c, qkv, M * 3 * C); f16* o = c.ws.get<f16>(M * C);
-    FlashP p; p.Q = dq; p.K = dq + C; p.V = dq + 2 * C; p.ldq = p.ldk = p.ldv = 3 * C; p.O = o; p.ldo = C; p.B = B; p.H = H; p.S = S;
+    FlashP p; p.variant = c.flash_variant; p.Q = dq; p.K = dq + C; p.V = dq + 2 * C; p.ldq = p.ldk = p.ldv = 3 * C; p.O = o; p.ldo = C; p.B = B; p.H = H; p.S = S;
     p.scale = 1.0f / sqrtf((float)d);
     launch_flash_attn_dh(p, d, c.stream);
     down16(c, o, out, M * C);
   });
 }
 
+int ug_bench_mfma_peak(ug_ctx* x, int iters, float* tflops_out) {
+  UG_TRY(x, {
+    Ctx& c = x->c; Scope sc(c);
+    float* scratch = c.ws.get<float>(256 * 512);
+    *tflops_out = bench_mfma_peak(scratch, iters > 0 ? iters : 20000, c.stream);
+  });
+}
 int ug_tune_force(ug_ctx* x, int cfg, int split) {
   if (!x) return -1;
   if (cfg <= -100) x->c.tune.knobs = -cfg - 100;             // knob mask: ug_tune_force(ctx, -100 - knobs, 0)
   else { x->c.tune.cfg = cfg; x->c.tune.split = split; }
+  x->c.lane_need.clear();    // forced split-K / tile configs change the partial buffers a lane task needs
   return 0;
 }
-int ug_tune_flash(int variant) { flash_set_variant(variant); return 0; }
-int ug_tune_ff(int variant) { ff_fused_set_variant(variant); return 0; }
+int ug_tune_flash(ug_ctx* x, int variant) { if (!x) return -1; x->c.flash_variant = variant; return 0; }
+int ug_tune_ff(ug_ctx* x, int variant) { if (!x) return -1; x->c.ff_variant = variant; x->c.lane_need.clear(); return 0; }
 
 // GEMM / conv microbenchmark on device-resident pseudo-random data: average ms per launch over `iters`.
 int ug_bench_gemm(ug_ctx* x, int M, int N, int K, int conv, int T, int Hi, int Wi, int C0, int C1, int kt, int k,

@@ -106,15 +106,10 @@ struct FFusedP {
   //   x' = fp16(X + addvec[row / rows_per_vec]) (addvec optional), X_used = fp16(LayerNorm(x') * ln_g + ln_b);
   // with addvec the R1 residual is taken as fp16(R1 + addvec[...]) as well (R1 == X: the block's residual stream)
   const f16* ln_g; const f16* ln_b; float ln_eps; const f16* addvec; int rows_per_vec;
+  int variant;            // 0 = default (cross-tile prefetch), 1 = without it (A/B; Ctx::ff_variant, ug_tune_ff)
 };
-// LayerNorm -> linear for the narrow blocks (kernels/ff_fused.hip, ln_linear_kernel): Out[M, N] (row stride ldo) = LN(X)[M, C] . W^T + bias, W [N][C];
-// ln_g == nullptr skips the LayerNorm (a plain X-resident projection)
-struct LnLinP { const f16* X; const f16* W; const f16* bias; f16* Out; long ldo; int M, C, N; const f16* ln_g; const f16* ln_b; float ln_eps; };
-bool ln_linear_supported(int C, int N);
-void launch_ln_linear(const LnLinP& p, hipStream_t s);
 bool ff_fused_supported(int C);
 void launch_ff_fused(const FFusedP& p, hipStream_t s);
-void ff_fused_set_variant(int v);   // A/B aid (ug_tune_ff): 1 = GEGLU pipelined across chunks (default), 0 = round-2 kernel
 
 // ---------------------------------------------------------------------------------------
 // Normalisation (kernels/norm.hip)
@@ -127,11 +122,8 @@ struct GroupNormP {
   const f16* gamma; const f16* beta;
   f16* Y;                 // [T*HW, C0+C1]
   float* ws;              // >= T * G * 2 * nchunk floats (+ T*G*2 for mean/rstd)
-  int mode;               // 0 = automatic; 1 / 2 / 3 force a launch scheme (launch_groupnorm: three launches / one workgroup per group / one launch, rows in registers)
-  void* sync; unsigned tag;   // one-launch scheme: a zero-initialised GnSync block owned by the caller's context (per stream) and a tag unique to this launch;
-                              // sync == nullptr keeps the other schemes
+  int mode;               // 0 = automatic; 1 / 2 / 4 / 6 force a launch scheme (launch_groupnorm)
 };
-size_t groupnorm_sync_bytes();
 void launch_groupnorm(const GroupNormP& p, hipStream_t s);
 size_t groupnorm_ws_floats(int T, int HW, int C, int G);
 
@@ -159,13 +151,12 @@ struct FlashP {
   f16* O; long ldo;
   int B, H, S; float scale;
   int Sk = 0; int kv_shared = 0;
-  int variant = -1;   // A/B aid (tools/bench_flash.py): -1 = the process default (7), else a bit mask - 1 = one softmax step per 64 keys, 2 = XCD-grouped
+  int variant = -1;   // A/B aid (tools/bench_flash.py; Ctx::flash_variant, ug_tune_flash): -1 = the default form (23), else a bit mask - 1 = one softmax step per 64 keys, 2 = XCD-grouped
                       // workgroup order, 4 = 2-slot K/V ring + 4 workgroups per CU
 };
 void launch_flash_attn64(const FlashP& p, hipStream_t s);
 bool flash_attn_dh_supported(int d);
 void launch_flash_attn_dh(const FlashP& p, int d, hipStream_t s);   // self-attention with head dim d in {32, 48, 80, 96, 112, 128} (CLIP ViT-H/14: 80)
-void flash_set_variant(int v);   // test aid: the process default of FlashP::variant (ug_tune_flash)
 
 // Temporal self-attention: for every pixel p and head h, sequence over the T frames
 // (row of frame t = t*HW + p), head_dim 64, T <= 128 (BASELINE config 5 uses 50-frame clips; upstream DepthCrafter's default window is 110 frames).
@@ -241,6 +232,9 @@ void launch_gn32_pair(const float* X, f16* Y, int T, int HW, int C, int G, float
 void launch_qk_terms(const float* qkv, f16* Aq, f16* Bk, long M, int C, hipStream_t s);
 void launch_vt_terms(const float* qkv, f16* Vt, int B, int S, int Spad, int C, hipStream_t s);
 void launch_softmax_pair(const float* in, long ld_in, f16* out, int Spad, long rows, int S, hipStream_t s);
+
+// calibration probe (kernels/probe.hip): chip-wide fp16 MFMA rate, operands in registers; scratch >= 256 * 512 floats
+float bench_mfma_peak(float* scratch, int iters, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // Evaluation metrics on device (kernels/metrics.hip)

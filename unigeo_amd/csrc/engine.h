@@ -169,15 +169,12 @@ struct Ctx {
                              // bit-identical.  Measured on the 25 x 384 x 512 clip: 2 lanes -0.6 %, 3 lanes +-0 - the persistent GEMMs fill the
                              // register file of every CU, so a second stream's kernels only get the tail rounds
   std::map<std::string, size_t> lane_need;
-  // one-launch GroupNorm (kernels/norm.hip: gn_fused): zero-initialised hand-off blocks, one per stream (0 = the main stream, 1.. = lanes), and the
-  // launch tag; gn_fused_on = 1 selects it (A/B, ug_set_gn_fused)
-  char* gn_sync = nullptr; unsigned gn_tag = 0; int cur_lane = 0; int gn_fused_on = 0;   // measured SLOWER than three launches (45 vs 40 us at level 0): off
+  int cur_lane = 0;          // 0 = main stream, l + 1 = lane l (run_lanes)
+  int ff_variant = 0, flash_variant = -1;   // ug_tune_ff / ug_tune_flash: per-context A/B overrides copied into FFusedP / FlashP (0 / -1 = the defaults)
   GemmTune tune;             // ug_tune_force: tile-config / split-K / knob overrides for THIS context's GEMM launches (tests, A/B tools)
 };
 
 void* pinned(Ctx& c, int slot, size_t bytes);   // page-locked staging buffer of at least `bytes`
-void gn_attach(Ctx& c, GroupNormP& p);          // hand a GroupNorm launch its stream's hand-off block and a fresh tag (one-launch scheme)
-void gn_check(Ctx& c);                          // after a stream sync: throw if a GroupNorm hand-off timed out (and reset the blocks)
 
 // ---- binding ----
 void upload_raw(Ctx& c, const std::string& name, int dtype, const std::vector<long>& shape, const void* host);

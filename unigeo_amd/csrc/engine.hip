@@ -40,7 +40,6 @@ struct RunGuard {
   ~RunGuard() {
     (void)hipStreamSynchronize(c.stream);
     for (auto& l : c.lanes) (void)hipStreamSynchronize(l.stream);
-    if (std::uncaught_exceptions() > 0 && c.gn_sync) (void)hipMemset(c.gn_sync, 0, groupnorm_sync_bytes() * 9);   // a call that died mid-way may leave tickets half counted
     c.ws.release(mk);
     c.unet.tproj = nullptr; c.unet.tproj_steps = 0;
     auto forget = [](Transformer& t) { t.frame_emb = nullptr; t.frame_emb_T = 0; t.cross_sp = nullptr; t.cross_tm = nullptr; };
@@ -227,30 +226,6 @@ static void run_gemm(Ctx& c, GemmP p, int batch, const char* tag, float alg = 1.
   c.ws.release(mk);
 }
 
-static constexpr int kGnSyncSlots = 9;      // main stream + up to 8 lanes
-void gn_attach(Ctx& c, GroupNormP& p) {
-  if (!c.gn_fused_on) { p.sync = nullptr; return; }
-  if (!c.gn_sync) {
-    c.gn_sync = (char*)c.persist.alloc(groupnorm_sync_bytes() * kGnSyncSlots);
-    UG_CHECK(hipMemsetAsync(c.gn_sync, 0, groupnorm_sync_bytes() * kGnSyncSlots, c.stream));
-  }
-  p.sync = c.gn_sync + (size_t)std::min(c.cur_lane, kGnSyncSlots - 1) * groupnorm_sync_bytes();
-  p.tag = ++c.gn_tag;
-  if (p.tag == 0) p.tag = ++c.gn_tag;       // 0 is what a fresh block holds
-}
-void gn_check(Ctx& c) {
-  if (!c.gn_sync) return;
-  std::vector<unsigned> h(groupnorm_sync_bytes() * kGnSyncSlots / 4);
-  UG_CHECK(hipMemcpy(h.data(), c.gn_sync, h.size() * 4, hipMemcpyDeviceToHost));
-  const size_t per = groupnorm_sync_bytes() / 4;
-  bool bad = false;
-  for (int i = 0; i < kGnSyncSlots; ++i) bad |= h[i * per + 258] != 0;      // GnSync::err
-  if (bad) {
-    UG_CHECK(hipMemset(c.gn_sync, 0, groupnorm_sync_bytes() * kGnSyncSlots));
-    throw std::runtime_error("GroupNorm hand-off timed out (one-launch scheme): results of this call are invalid; ug_set_gn_fused(ctx, 0) selects the three-launch scheme");
-  }
-}
-
 void* pinned(Ctx& c, int slot, size_t bytes) {
   if (c.pin_sz[slot] < bytes) {
     if (c.pin[slot]) UG_CHECK(hipHostFree(c.pin[slot]));
@@ -353,7 +328,6 @@ static void groupnorm(Ctx& c, const f16* x0, int C0, const f16* x1, int C1, int 
   p.temporal = temporal; p.silu = silu; p.gamma = n.g; p.beta = n.b; p.Y = y;
   const size_t mk = c.ws.mark();
   p.ws = c.ws.get<float>((long)groupnorm_ws_floats(T, HW, n.c, G));
-  gn_attach(c, p);
   {
     char nm[96];
     if (c.prof_on && c.prof_shapes) snprintf(nm, sizeof(nm), "groupnorm:T%dxHW%dxC%d%s", T, HW, n.c, temporal ? "t" : "");
@@ -948,7 +922,7 @@ static void ff_pair(Ctx& c, const f16* a, long M, const Lin& f1, const Lin& f2, 
   if (ff_pair_fusable(c, M, f1, f2, e2) && !no_fuse) {
     FFusedP p; memset(&p, 0, sizeof(p));
     p.X = a; p.W1 = f1.w; p.b1 = f1.b; p.W2 = f2.w; p.b2 = f2.b; p.R1 = e2.R1; p.R2 = e2.R2; p.c0 = e2.c0; p.c1 = e2.c1; p.c2 = e2.c2;
-    p.Out = out; p.M = (int)M; p.C = C; p.zero = c.zero;
+    p.Out = out; p.M = (int)M; p.C = C; p.zero = c.zero; p.variant = c.ff_variant;
     if (pre) { p.ln_g = pre->g; p.ln_b = pre->b; p.ln_eps = pre->eps; p.addvec = pre->addvec; p.rows_per_vec = (int)pre->rows_per_vec; }
     char nm[64];
     if (c.prof_on && c.prof_shapes) snprintf(nm, sizeof(nm), "gemm_ff_fused:%ldx%d", M, C); else snprintf(nm, sizeof(nm), "gemm_ff_fused");
@@ -973,19 +947,9 @@ static void ff_pair(Ctx& c, const f16* a, long M, const Lin& f1, const Lin& f2, 
   }
 }
 
-// out[M, l.out] = LayerNorm(x) . W^T (+ bias): on the narrow level (C <= 320, long tensors) ONE kernel with the activation tile resident in LDS
-// (kernels/ff_fused.hip: ln_linear_kernel) - the Q | K | V projections of the spatial and temporal attention; otherwise the LayerNorm launch
-// (writing t1) followed by the GEMM.  c.ff_fused bit 2 switches the fusion (A/B, parity tests).
+// out[M, l.out] = LayerNorm(x) . W^T (+ bias): the LayerNorm launch (writing t1) followed by the GEMM.  (Round 3 also had ONE kernel with the
+// activation tile resident in LDS for the narrow level; 130 - 137 us against 113 - 117 for the pair at 76800 x 960 x 320 - removed in round 4.)
 static void ln_linear(Ctx& c, const f16* x, long M, const Norm& ln, f16* t1, const Lin& l, f16* out, const QAct* q) {
-  if ((c.ff_fused & 4) && !c.fp8_linears && ln.g && ln.b && M >= 32768 && ln_linear_supported(l.in, l.out) && (long)M * l.out < (1L << 30)) {
-    LnLinP p; memset(&p, 0, sizeof(p));
-    p.X = x; p.W = l.w; p.bias = l.b; p.Out = out; p.ldo = l.out; p.M = (int)M; p.C = l.in; p.N = l.out; p.ln_g = ln.g; p.ln_b = ln.b; p.ln_eps = ln.eps;
-    char nm[64];
-    if (c.prof_on && c.prof_shapes) snprintf(nm, sizeof(nm), "gemm_ln_linear:%ldx%dx%d", M, l.out, l.in); else snprintf(nm, sizeof(nm), "gemm_ln_linear");
-    ProfScope ps(c, nm, 2.0 * M * (double)l.out * l.in, 2.0 * ((double)M * l.in + (double)l.out * l.in + (double)M * l.out));
-    launch_ln_linear(p, c.stream);
-    return;
-  }
   layernorm(c, x, M, ln, t1, nullptr, 1, nullptr, q);
   Epi e;
   if (q) { e.a8 = q->a8; e.sa8 = q->sa; e.ld_sa8 = q->ld; }
@@ -1044,7 +1008,7 @@ static f16* transformer_forward(Ctx& c, const Transformer& tr, const f16* x, int
   f16* ao = c.ws.get<f16>(M * C);
   {
     FlashP p; p.Q = qkv; p.K = qkv + C; p.V = qkv + 2 * C; p.ldq = p.ldk = p.ldv = 3 * C; p.O = ao; p.ldo = C;
-    p.B = T; p.H = tr.heads; p.S = HW; p.scale = 0.125f;
+    p.B = T; p.H = tr.heads; p.S = HW; p.scale = 0.125f; p.variant = c.flash_variant;
     char nm[96];
     if (c.prof_on && c.prof_shapes) snprintf(nm, sizeof(nm), "flash_attn:B%dxH%dxS%d", T, tr.heads, HW);
     else snprintf(nm, sizeof(nm), "flash_attn");
@@ -1649,7 +1613,6 @@ void dc_run(Ctx& c, int steps, int chunk, int with_normals, int window, int over
     launch_normals(c.d_depth, c.d_K, c.d_normals, T, H, W, c.stream);
   }
   UG_CHECK(hipStreamSynchronize(c.stream));
-  gn_check(c);
 }
 
 void dc_get_outputs(Ctx& c, float* frames, float* depth, float* normals) {

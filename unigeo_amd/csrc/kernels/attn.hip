@@ -263,9 +263,6 @@ __device__ __forceinline__ void fa_tile_wide(const f16* kt, const f16* vt, const
       }
 }
 
-static int g_fa_default = 23;   // process default of FlashP::variant (ug_tune_flash, a test aid): bit 0 = fa_tile_wide, bit 1 = XCD-grouped workgroup order, bit 2 = 2-slot ring + 4 workgroups per CU,
-                                // bit 4 = lazy rescale + dot2 row sums (needs bits 0-2), bit 5 = software-pipelined kernel
-void flash_set_variant(int v) { g_fa_default = v; }
 
 // The grid is 1-D: workgroup L runs on XCD L % 8, and each XCD has its own L2.  With the natural order the query blocks of one
 // (frame, head) are dealt round-robin to all 8 XCDs, so every L2 fetches that head's K / V for itself; the permutation below hands each
@@ -391,220 +388,6 @@ __global__ __launch_bounds__(256, OCC) void flash_attn64_kernel(const FlashP p, 
           *(f16x4*)(dst + dt * 32 + 8 * r4 + 4 * hh) = v;
         }
     }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Round 3: software-pipelined form.  What the counters and tools/microbench/mfma_vs_valu.hip say about the kernel above (profiles/r03_flash_pmc.txt,
-// r03_flash_ablation.txt, r03_mfma_vs_valu_microbench.txt): its matrix work (140 us at S = 3072), its LDS / staging skeleton (122 us) and its softmax
-// arithmetic (~100 us) ADD UP to the 380 us it takes - a wave runs them as separate phases, and the four waves of a SIMD (four workgroups
-// started together, one barrier per tile each) fall into the same phase; an MFMA of ANOTHER wave also blocks the VALU port for ~16 of its 32
-// cycles, one of the SAME wave for ~6.  So here every wave overlaps its own streams: in iteration t it multiplies the scores of tile t + 1
-// (K(t+1) Q^T, 8 MFMAs) while it runs the softmax of tile t on the VALU, then P(t) V(t).  K and V rings are offset by one tile (K(t+1) and
-// V(t) are the operands of iteration t); NST slots each.  Same numerics as the LAZY form above (reference moved only for > 2^8 growth, row
-// sums from the fp16 P by v_dot2).
-// ------------------------------------------------------------------------------------------
-template <int NST, int OCC>
-__global__ __launch_bounds__(256, OCC) void flash_attn64_pipe_kernel(const FlashP p, int nqb, int xcd_group) {
-  __shared__ __attribute__((aligned(16))) f16 lds[NST * 2 * FA_KV * 64];  // [K ring: NST x 64 x 64][V ring: NST x 64 x 64]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int Lw = blockIdx.x;
-  if (xcd_group) { const int per = gridDim.x >> 3; Lw = (Lw & 7) * per + (Lw >> 3); }
-  const int bx = Lw % nqb, bh = Lw / nqb;
-  const int h = bh % p.H, b = bh / p.H;
-  const int q0 = bx * 128 + wave * 32;
-  const long row0 = (long)b * p.S;
-  const int Sk = p.Sk ? p.Sk : p.S;
-  const long rowk = p.kv_shared ? 0 : (long)b * Sk;
-  const int qi = lane & 31, hh = lane >> 5;
-  const int L = lane & 15, db = ((lane >> 4) & 1) * 16;
-  const float sc = p.scale * 1.4426950408889634f;
-  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-  f16x8 qf[4];
-  const bool qok = (q0 + qi) < p.S;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    if (qok) qf[c] = *(const f16x8*)(p.Q + (row0 + q0 + qi) * p.ldq + h * 64 + c * 16 + hh * 8);
-    else qf[c] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-  }
-
-  f16* const kring = lds;
-  f16* const vring = lds + NST * FA_KV * 64;
-  const int srow0 = wave * 16 + (lane >> 3), pc = lane & 7;
-  const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)(p.K + rowk * p.ldk + h * 64), 0, (int)((((long)Sk - 1) * p.ldk + 64) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.V + rowk * p.ldv + h * 64), 0, (int)((((long)Sk - 1) * p.ldv + 64) * 2), 0x00020000);
-  int kvo[2], vvo[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int r = srow0 + j * 8;
-    kvo[j] = (int)((r * p.ldk + ((pc ^ kswz(r)) * 8)) * 2);
-    vvo[j] = (int)((r * p.ldv + ((pc ^ vswz(r)) * 8)) * 2);
-  }
-  const int kstep = (int)(FA_KV * p.ldk * 2), vstep = (int)(FA_KV * p.ldv * 2);
-  int kslot = 0, vslot = 0;                      // ring slots the next K / V tile goes to (tiles are staged in order)
-  auto stage_k = [&]() {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (lptr_t)(kring + kslot * (FA_KV * 64) + (wave * 16 + j * 8) * 64), 16, kvo[j], 0, 0, 0);
-      kvo[j] += kstep;
-    }
-    if (++kslot == NST) kslot = 0;
-  };
-  auto stage_v = [&]() {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (lptr_t)(vring + vslot * (FA_KV * 64) + (wave * 16 + j * 8) * 64), 16, vvo[j], 0, 0, 0);
-      vvo[j] += vstep;
-    }
-    if (++vslot == NST) vslot = 0;
-  };
-  // scores of one K tile: two interleaved accumulate chains (32 keys each)
-  auto qk = [&](const f16* kt, f32x16 (&s)[2]) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      f16x8 kf[2];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) { const int row = kb * 32 + qi; kf[kb] = *(const f16x8*)(kt + row * 64 + (((c * 2 + hh) ^ kswz(row)) * 8)); }
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb], qf[c], c == 0 ? zero16 : s[kb], 0, 0, 0);
-    }
-  };
-
-  f32x16 o[2] = {zero16, zero16};
-  float m_run = -1e30f, l_run = 0.f;
-  const int ntile = (Sk + FA_KV - 1) / FA_KV;
-  const bool ragged = (Sk % FA_KV) != 0;
-
-  // prologue: K(0), then the pairs {K(u+1), V(u)} for u < NST - 1 (loads past the last key read zeros; 2 + 2 loads per thread and pair)
-  stage_k();
-#pragma unroll
-  for (int u = 0; u < NST - 1; ++u) { stage_k(); stage_v(); }
-  if (NST == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  f32x16 sn[2];
-  qk(kring, sn);
-  int kcur = 1 % NST, vcur = 0;                  // slots of K(t+1) and V(t)
-  for (int t = 0; t < ntile; ++t) {
-    // pair t = {K(t+1), V(t)} has landed (NST - 2 younger pairs may be in flight); everyone is done with K(t) and V(t-1)
-    if (NST == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    stage_k(); stage_v();                        // pair t + NST - 1 -> the slots of K(t) and V(t-1)
-    f32x16 s[2] = {sn[0], sn[1]};
-    if (ragged && t == ntile - 1) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = t * FA_KV + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (key >= Sk) s[kb][r] = -1e30f;
-        }
-    }
-    // next tile's scores are independent of everything below until the next iteration: their MFMAs are placed BETWEEN the groups of softmax
-    // VALU work in program order (a wave issues in order: an MFMA waiting for its predecessor in the accumulate chain would hold back
-    // whatever follows it), fragment reads one group ahead; sched_barrier keeps the compiler from regrouping
-    // (past the last tile the K slot holds the zero fill of an out-of-range load: the surplus scores are never used - no branch here)
-    const f16* ktn = kring + kcur * (FA_KV * 64);
-    f16x8 kf[2][2];
-    auto kread = [&](int c, f16x8 (&d)[2]) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) { const int row = kb * 32 + qi; d[kb] = *(const f16x8*)(ktn + row * 64 + (((c * 2 + hh) ^ kswz(row)) * 8)); }
-    };
-    auto kmma = [&](int c, const f16x8 (&d)[2]) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(d[kb], qf[c], c == 0 ? zero16 : sn[kb], 0, 0, 0);
-    };
-    const f16* vt = vring + vcur * (FA_KV * 64);
-    f16x8 pb[2][2];
-    f16x8 va[2][2];                                // [slot][dt]: V^T fragments of one (kb, a) step, read one group ahead
-    float ps = 0.f;
-    auto vread = [&](int kb, int a2, f16x8 (&d)[2]) {
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int h2i = 0; h2i < 2; ++h2i) {
-          const int vrow = kb * 32 + 16 * a2 + 8 * h2i + 4 * hh + (L >> 2);
-          const int col = dt * 32 + db + (L & 3) * 4;
-          const int chunk = (col >> 3) ^ vswz(vrow);
-          const f16x4 tv = lds_tr16(vt + vrow * 64 + chunk * 8 + (col & 7));
-          d[dt][4 * h2i + 0] = tv[0]; d[dt][4 * h2i + 1] = tv[1]; d[dt][4 * h2i + 2] = tv[2]; d[dt][4 * h2i + 3] = tv[3];
-        }
-    };
-    auto pv = [&](int kb, int a2, const f16x8 (&d)[2]) {
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(d[dt], pb[kb][a2], o[dt], 0, 0, 0);
-    };
-    float nm = 0.f;
-    auto expg = [&](int kb, int a2) {               // 8 scores -> the fp16 P fragment of one (kb, a) step + their row sum
-#pragma unroll
-      for (int r = a2 * 8; r < a2 * 8 + 8; r += 2) {
-        const f16x2 h2 = {(f16)__builtin_amdgcn_exp2f(fmaf(s[kb][r], sc, nm)), (f16)__builtin_amdgcn_exp2f(fmaf(s[kb][r + 1], sc, nm))};
-        ps = __builtin_amdgcn_fdot2(h2, (f16x2){(f16)1.f, (f16)1.f}, ps, false);
-        pb[kb][a2][r & 7] = h2.x;
-        pb[kb][a2][(r & 7) + 1] = h2.y;
-      }
-    };
-#define UG_SB __builtin_amdgcn_sched_barrier(0)
-    kread(0, kf[0]); kread(1, kf[1]);
-    UG_SB; kmma(0, kf[0]); UG_SB;
-    float mx = -1e30f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
-    kread(2, kf[0]);
-    UG_SB; kmma(1, kf[1]); UG_SB;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-    kread(3, kf[1]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    UG_SB;
-    if (__any(mx * sc > m_run + 8.0f)) {
-      const float m_new = fmaxf(m_run, mx * sc);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      l_run *= alpha;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-      m_run = m_new;
-    }
-    nm = -m_run;
-    UG_SB; kmma(2, kf[0]); UG_SB;
-    expg(0, 0);
-    vread(0, 0, va[0]);
-    UG_SB; kmma(3, kf[1]); UG_SB;
-    expg(0, 1);
-    vread(0, 1, va[1]);
-    UG_SB; pv(0, 0, va[0]); UG_SB;
-    expg(1, 0);
-    vread(1, 0, va[0]);
-    UG_SB; pv(0, 1, va[1]); UG_SB;
-    expg(1, 1);
-    vread(1, 1, va[1]);
-    UG_SB; pv(1, 0, va[0]); UG_SB;
-    l_run += ps;
-    pv(1, 1, va[1]);
-#undef UG_SB
-    if (++kcur == NST) kcur = 0;
-    if (++vcur == NST) vcur = 0;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-filled pairs past the last tile: no LDS-DMA may outlive the workgroup
-  float l = l_run;
-  l += __shfl_xor(l, 32);
-  const float inv = 1.0f / l;
-  if (qok) {
-    f16* dst = p.O + (row0 + q0 + qi) * p.ldo + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        f16x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (f16)(o[dt][r4 * 4 + e] * inv);
-        *(f16x4*)(dst + dt * 32 + 8 * r4 + 4 * hh) = v;
-      }
   }
 }
 
@@ -819,8 +602,9 @@ void launch_flash_attn64(const FlashP& p, hipStream_t s) {
   const int nqb = cdiv(p.S, 128 * FA_QB);
   const long total = (long)nqb * p.H * p.B;
   UG_REQUIRE(total < (1L << 31), "flash attention grid");
-  const int g_fa_wide = p.variant >= 0 ? p.variant : g_fa_default;
+  const int g_fa_wide = p.variant >= 0 ? p.variant : 23;   // default: wide tiles, XCD-grouped order, 2-slot ring / 4 workgroups per CU, lazy rescale + dot2 row sums
   const int xcd_group = (total % 8 == 0 && (g_fa_wide & 2)) ? 1 : 0;
+#ifdef UG_EXPERIMENTS
   if (g_fa_wide >= 1000) {   // timing-only ablations (1000 + mask) of the default form (wide, 2-slot ring, 4 workgroups per CU)
     switch (g_fa_wide - 1000) {
 #define UG_FA_ABL(A) case A: hipLaunchKernelGGL((flash_attn64_kernel<true, 2, 4, A>), dim3((unsigned)total), dim3(256), 0, s, p, nqb, total % 8 == 0 ? 1 : 0); break;
@@ -828,14 +612,16 @@ void launch_flash_attn64(const FlashP& p, hipStream_t s) {
 #undef UG_FA_ABL
       default: UG_REQUIRE(false, "unknown flash ablation");
     }
-  } else if (g_fa_wide & 64) {            // bit 6: 8-wave ping-pong kernel (512 query rows per workgroup)
+    UG_CHECK(hipGetLastError());
+    return;
+  }
+#endif
+  if (g_fa_wide & 64) {            // bit 6: 8-wave ping-pong kernel (512 query rows per workgroup)
     const int nq8 = cdiv(p.S, 512);
     const dim3 g8((unsigned)((long)nq8 * p.H * p.B));
     if (g_fa_wide & 128) hipLaunchKernelGGL(flash_attn64_pp_kernel<1>, g8, dim3(512), 0, s, p, nq8);
     else if (g_fa_wide & 256) hipLaunchKernelGGL(flash_attn64_pp_kernel<2>, g8, dim3(512), 0, s, p, nq8);
     else hipLaunchKernelGGL(flash_attn64_pp_kernel<0>, g8, dim3(512), 0, s, p, nq8);
-  } else if (g_fa_wide & 32) {            // bit 5: software-pipelined kernel (3-slot rings, 3 workgroups per CU)
-    hipLaunchKernelGGL((flash_attn64_pipe_kernel<3, 3>), dim3((unsigned)total), dim3(256), 0, s, p, nqb, xcd_group);
   } else if ((g_fa_wide & 31) == 23) {   // bit 4: lazy rescale + dot2 row sums (default)
     hipLaunchKernelGGL((flash_attn64_kernel<true, 2, 4, 0, true>), dim3((unsigned)total), dim3(256), 0, s, p, nqb, xcd_group);
   } else if (g_fa_wide & 4) {   // A/B: 2-slot ring (32 KiB) and 4 workgroups per CU

@@ -360,563 +360,8 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------------------------------
-// Round 3: the same kernel with the GEGLU of chunk j software-pipelined into the phase-A MFMAs of chunk j + 1 (two acc1 buffers).
-// Measured first (tools/bench_ff.py, profiles/r03_ff_variants.txt): a four-wave form (one wave per SIMD, 64 x 64 wave tiles, 4-slot ring,
-// hand-pipelined fragment reads, half the barriers per FLOP) ran at exactly the eight-wave kernel's speed (281 vs 280 us at M = 76800) - a
-// single in-order wave has to ISSUE the packet's 32 MFMAs, 4 LDS-DMA loads, 16 fragment reads and its share of the GEGLU (~160 VALU) one
-// after the other (~1100 issue cycles against 544 cycles of matrix pipe), so what limits this kernel is issue bandwidth per wave, not
-// barriers or LDS reads.  Two waves per SIMD issue different instruction types in the same cycle; what they cannot do in the round-2 kernel
-// is overlap the GEGLU, because both reach the end of phase A at the same barrier.  Same arithmetic, same order: bit-identical outputs.
-template <int KT>
-__global__ __launch_bounds__(512, 2) void ff_fused_pipe_kernel(const FFusedP p) {
-  constexpr int C = KT * 64;
-  constexpr int NP = (C + 127) / 128;          // phase-B pieces: NPF full ones of 128 output columns + (C % 128 == 64) one of 64
-  constexpr int NPF = C / 128;
-  constexpr bool TAIL = (C % 128) != 0;
-  constexpr int STEPS = KT + NP;               // packets per chunk
-  constexpr int TILE = 128 * 64;               // halves per [128 x 64] tile
-  extern __shared__ __attribute__((aligned(16))) f16 smem[];
-  f16* Xs = smem;                              // [KT][128][64]
-  f16* ring = smem + KT * TILE;                // [3][128][64]
-  f16* Gs = ring + 3 * TILE;                   // [128][64]
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l15 = lane & 15, g = lane >> 4;
-  const int sw = ffswz(l15);
-  const int pc = lane & 7, lrow = lane >> 3;
-  const int I = 4 * C;                         // inner width (GEGLU outputs); W1 has 2*I rows
-  const int nchunk = I / 64;
-  const int ntiles = (p.M + 127) / 128;
-
-  // ---- buffer-addressed direct-to-LDS loads: the per-lane byte offset of every load is fixed for the whole kernel (row permutation,
-  // swizzled 16-byte chunk), the packet position is a scalar offset - no address arithmetic on the issue path
-  constexpr unsigned SENT = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t rW1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.W1, 0, (int)SENT, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rW2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.W2, 0, (int)SENT, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (int)((long)p.M * C * 2), 0x00020000);   // rows >= M read zeros
-  unsigned vo1[2], vo2[2], vot, vox;
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {   // LDS row lr holds weight row perm(lr): wave tile 64, 16 contiguous columns per lane
-    const int lr = (wave * 2 + u) * 8 + lrow;
-    const int part = lr >> 6, rem = lr & 63, jj = rem >> 4, i = rem & 15;
-    const int n = part * 64 + (i >> 2) * 16 + jj * 4 + (i & 3);
-    vo1[u] = (unsigned)((n * C + (pc ^ ffswz(lr)) * 8) * 2);
-    vo2[u] = (unsigned)((n * I + (pc ^ ffswz(lr)) * 8) * 2);
-  }
-  {   // tail piece: 64 output columns, wave tile 32 (8 columns per lane)
-    const int lr = wave * 8 + lrow;
-    const int part = lr >> 5, rem = lr & 31, jj = rem >> 4, i = rem & 15;
-    const int n = NPF * 128 + part * 32 + (i >> 2) * 8 + jj * 4 + (i & 3);
-    vot = (unsigned)((n * I + (pc ^ ffswz(lr)) * 8) * 2);
-  }
-  vox = (unsigned)((lrow * C + 0) * 2);   // X rows: + (r*8) rows and the swizzled chunk are added per load (the swizzle depends on r)
-  auto issue_packet = [&](int j, int s, int slot) {
-    f16* dst = ring + slot * TILE;
-    if (s < KT) {   // W1 rows [j*128, +128), K tile s
-      const int so = (j * 128 * C + s * 64) * 2;
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW1, (lptr_t)(dst + (wave * 2 + u) * 8 * 64), 16, (int)vo1[u], so, 0, 0);
-    } else if (s - KT < NPF) {   // W2 rows [pp*128, +128) (output columns), K columns [j*64, +64)
-      const int so = ((s - KT) * 128 * I + j * 64) * 2;
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW2, (lptr_t)(dst + (wave * 2 + u) * 8 * 64), 16, (int)vo2[u], so, 0, 0);
-    } else {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW2, (lptr_t)(dst + wave * 8 * 64), 16, (int)vot, j * 64 * 2, 0, 0);
-    }
-  };
-  // loads per wave of packet s (compile-time when s is)
-  auto nload = [](int s) { return (TAIL && s == STEPS - 1) ? 1 : 2; };
-
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int m0 = tile * 128;
-    // ---- X tile: KT x 16 wave-instructions of 1 KiB, spread over the 8 waves
-    for (int t = wave; t < KT * 16; t += 8) {
-      const int kt = t >> 4, r = t & 15;
-      const int lr = r * 8 + lrow;
-      const unsigned vo = vox + (unsigned)((r * 8 * C + (pc ^ ffswz(lr)) * 8) * 2);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lptr_t)(Xs + kt * TILE + r * 8 * 64), 16, (int)vo, (m0 * C + kt * 64) * 2, 0, 0);
-    }
-    issue_packet(0, 0, 0);
-    if (KT > 1) issue_packet(0, 1, 1); else issue_packet(1, 0, 1);     // second packet of the stream: A(0, 1), or A(1, 0) when a chunk has one K tile
-
-    if (p.ln_g) {
-      // ---- pre-norm on the LDS tile: 4 threads per token row (2 chunks of 8 channels in each of the KT K tiles), exact two-pass
-      // statistics in fp32 - the values launch_layernorm would have written to HBM and this kernel would have read back.
-      // gamma / beta / the broadcast row are fetched BEFORE the wait for the X tile, so their latency hides behind the tile's.
-      const int row = tid >> 2, q4 = tid & 3;
-      const long mr = (long)m0 + row < p.M ? (long)m0 + row : (long)p.M - 1;
-      const f16* av = p.addvec ? p.addvec + (long)((int)mr / p.rows_per_vec) * C : nullptr;
-      f16x8 ga[KT][2], be[KT][2], ad[KT][2];
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          ga[kt][u] = *(const f16x8*)(p.ln_g + kt * 64 + q4 * 16 + u * 8);
-          be[kt][u] = *(const f16x8*)(p.ln_b + kt * 64 + q4 * 16 + u * 8);
-          if (av) ad[kt][u] = *(const f16x8*)(av + kt * 64 + q4 * 16 + u * 8);
-        }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      f16* xr = Xs + row * 64;
-      const int cs[2] = {((q4 * 2) ^ ffswz(row)) * 8, ((q4 * 2 + 1) ^ ffswz(row)) * 8};   // this thread's two chunks of every K tile
-      f16x8 hx[KT][2];
-      float sum = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          hx[kt][u] = *(const f16x8*)(xr + kt * TILE + cs[u]);
-          if (av) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) hx[kt][u][e] = (f16)((float)hx[kt][u][e] + (float)ad[kt][u][e]);
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) sum += (float)hx[kt][u][e];
-        }
-      sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
-      const float mean = sum / C;
-      float var = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { const float d = (float)hx[kt][u][e] - mean; var += d * d; }
-      var += __shfl_xor(var, 1); var += __shfl_xor(var, 2);
-      const float rstd = rsqrtf(var / C + p.ln_eps);
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          f16x8 y;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) y[e] = (f16)(((float)hx[kt][u][e] - mean) * rstd * (float)ga[kt][u][e] + (float)be[kt][u][e]);
-          *(f16x8*)(xr + kt * TILE + cs[u]) = y;
-        }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the first packet's barrier below publishes the normalised tile
-    }
-
-    f32x4 acc1[2][2][4], acc2[NP][2][4];      // acc1[parity]: phase-A accumulators of two consecutive chunks
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jn = 0; jn < 4; ++jn) {
-        acc1[0][i][jn] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[1][i][jn] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int pp = 0; pp < NP; ++pp) acc2[pp][i][jn] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-
-    // Packet stream of a tile, in "super-steps" t = 0 .. nchunk: [phase A of chunk t (KT packets, absent for t = nchunk)] then [phase B of
-    // chunk t - 1 (NP packets, absent for t = 0)].  The GEGLU of chunk t - 1 (bias, erf-GELU gate, fp16 rounding, G tile store: ~320 VALU
-    // instructions per wave) is spread over the phase-A packets of chunk t, which accumulate into the OTHER acc1 buffer - so its VALU work
-    // issues in the shadow of MFMAs instead of stalling the matrix pipe once per chunk (both waves of a SIMD reach the end of phase A together).
-    auto advance = [&](int& t, int& pos) {
-      ++pos;
-      if (t == 0 && pos == KT) { t = 1; pos = 0; }
-      else if (pos == STEPS) { ++t; pos = (t == nchunk) ? KT : 0; }
-    };
-    auto issue_at = [&](int t, int pos, int slot_) {
-      if (t > nchunk || (t == nchunk && pos < KT)) return;
-      if (pos < KT) issue_packet(t, pos, slot_); else issue_packet(t - 1, pos, slot_);
-    };
-    constexpr int GU = (8 + KT - 1) / KT;     // GEGLU units (one ff_geglu2 call = 2 outputs of one row block) per phase-A packet
-
-    int slot = 0;
-    bool first = true;
-    // one super-step; PAR = parity of t (compile-time so that acc1[PAR] / acc1[PAR ^ 1] are registers)
-    auto superstep = [&](int t, auto par_c) {
-      constexpr int PAR = decltype(par_c)::value;
-      const bool hasA = t < nchunk, hasB = t > 0;
-      f16x8 b0, b1v;
-      if (hasB) {   // bias of chunk t - 1's GEGLU rows: W1 rows (t-1)*128 + wn*64 + g*16 + [0,16) = [8 value | 8 gate]
-        b0 = *(const f16x8*)(p.b1 + (t - 1) * 128 + wn * 64 + g * 16); b1v = *(const f16x8*)(p.b1 + (t - 1) * 128 + wn * 64 + g * 16 + 8);
-      }
-      f16x8 og[2];
-      auto geglu_units = [&](int u0, int u1) {   // units [u0, u1) of the previous chunk's GEGLU, from acc1[PAR ^ 1]
-#pragma unroll
-        for (int u = u0; u < u1; ++u) {
-          const int i = u >> 2, e = (u & 3) * 2;
-          // value rows: MFMA blocks jn = 0,1 (8 rows), gate rows: jn = 2,3; output column pair (e, e+1) of this lane's 8
-          const float h0 = acc1[PAR ^ 1][i][e >> 2][e & 3] + (float)b0[e], h1 = acc1[PAR ^ 1][i][(e + 1) >> 2][(e + 1) & 3] + (float)b0[e + 1];
-          const float g0 = acc1[PAR ^ 1][i][2 + (e >> 2)][e & 3] + (float)b1v[e], g1 = acc1[PAR ^ 1][i][2 + ((e + 1) >> 2)][(e + 1) & 3] + (float)b1v[e + 1];
-          const f32x2 r2 = ff_geglu2((f32x2){h0, h1}, (f32x2){g0, g1});
-          og[i][e] = (f16)r2.x; og[i][e + 1] = (f16)r2.y;
-          if ((u & 3) == 3) {
-            const int row = wm * 32 + i * 16 + l15;
-            *(f16x8*)(Gs + row * 64 + (((wn * 4 + g) ^ ffswz(row)) * 8)) = og[i];
-#pragma unroll
-            for (int jn = 0; jn < 4; ++jn) acc1[PAR ^ 1][i][jn] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          }
-        }
-      };
-      if (hasB && !hasA) geglu_units(0, 8);      // last super-step: nothing left to hide it under
-#pragma unroll
-      for (int s = 0; s < STEPS; ++s) {
-        if (s < KT && !hasA) continue;
-        if (s >= KT && !hasB) continue;
-        const bool last = (t == nchunk) && (s == STEPS - 1);
-        // the packet after this one (its load count decides how many loads may stay in flight)
-        int tn = t, sn = s; advance(tn, sn);
-        if (first || last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (TAIL && sn == STEPS - 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        first = false;
-        if (s == KT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's G-tile writes are done before the barrier publishes them
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        {
-          int t2 = tn, s2 = sn; advance(t2, s2);
-          int slot2 = slot + 2; if (slot2 >= 3) slot2 -= 3;
-          issue_at(t2, s2, slot2);
-        }
-        const f16* Wt = ring + slot * TILE;
-        if (++slot == 3) slot = 0;
-        if (s < KT) {
-          const f16* Ab = Xs + s * TILE + (wm * 32 + l15) * 64;
-          const f16* Bb = Wt + (wn * 64 + l15) * 64;
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk) {
-            const int ch = ((kk * 4 + g) ^ sw) * 8;
-            f16x8 bf[4], af[2];
-#pragma unroll
-            for (int jn = 0; jn < 4; ++jn) bf[jn] = *(const f16x8*)(Bb + jn * 16 * 64 + ch);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *(const f16x8*)(Ab + i * 16 * 64 + ch);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-              for (int jn = 0; jn < 4; ++jn) acc1[PAR][i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[jn], af[i], acc1[PAR][i][jn], 0, 0, 0);
-          }
-          if (hasB) geglu_units(s * GU < 8 ? s * GU : 8, (s + 1) * GU < 8 ? (s + 1) * GU : 8);
-        } else {
-          const int pp = s - KT;
-          const f16* Ab = Gs + (wm * 32 + l15) * 64;
-          const bool tailp = TAIL && pp == NP - 1;
-          const f16* Bb = Wt + ((tailp ? wn * 32 : wn * 64) + l15) * 64;
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk) {
-            const int ch = ((kk * 4 + g) ^ sw) * 8;
-            f16x8 bf[4], af[2];
-#pragma unroll
-            for (int jn = 0; jn < 4; ++jn)
-              if (!tailp || jn < 2) bf[jn] = *(const f16x8*)(Bb + jn * 16 * 64 + ch);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *(const f16x8*)(Ab + i * 16 * 64 + ch);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-              for (int jn = 0; jn < 4; ++jn)
-                if (!tailp || jn < 2) acc2[pp][i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[jn], af[i], acc2[pp][i][jn], 0, 0, 0);
-          }
-        }
-      }
-    };
-    superstep(0, std::integral_constant<int, 0>());
-    for (int t = 1; t + 1 < nchunk; t += 2) {       // nchunk = C / 16 is even: t = 1 .. nchunk - 2 in (odd, even) pairs
-      superstep(t, std::integral_constant<int, 1>());
-      superstep(t + 1, std::integral_constant<int, 0>());
-    }
-    superstep(nchunk - 1, std::integral_constant<int, 1>());
-    superstep(nchunk, std::integral_constant<int, 0>());
-
-    // ---- tile epilogue: out = c0 * (acc2 + b2) + c1 * R1 + c2 * R2; lane: rows wm*32 + i*16 + l15, 16 (tail: 8) contiguous columns
-#pragma unroll
-    for (int pp = 0; pp < NP; ++pp) {
-      const bool tailp = TAIL && pp == NP - 1;
-      const int wid = tailp ? 8 : 16;
-      const int n0 = pp * 128 + (tailp ? wn * 32 + g * 8 : wn * 64 + g * 16);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 32 + i * 16 + l15;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int e0 = 0; e0 < 16; e0 += 8) {
-          if (e0 >= wid) continue;
-          const f16x8 b = p.b2 ? *(const f16x8*)(p.b2 + n0 + e0) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-          float o[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) o[q] = p.c0 * (acc2[pp][i][(e0 + q) >> 2][(e0 + q) & 3] + (float)b[q]);
-          if (p.R1) {
-            f16x8 r = *(const f16x8*)(p.R1 + (long)m * C + n0 + e0);
-            if (p.ln_g && p.addvec) {   // the residual stream is x' = fp16(X + addvec) (see FFusedP)
-              const f16x8 a = *(const f16x8*)(p.addvec + ((long)m / p.rows_per_vec) * C + n0 + e0);
-#pragma unroll
-              for (int q = 0; q < 8; ++q) r[q] = (f16)((float)r[q] + (float)a[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) o[q] += p.c1 * (float)r[q];
-          }
-          if (p.R2) {
-            const f16x8 r = *(const f16x8*)(p.R2 + (long)m * C + n0 + e0);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) o[q] += p.c2 * (float)r[q];
-          }
-          f16x8 h;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) h[q] = (f16)o[q];
-          *(f16x8*)(p.Out + (long)m * C + n0 + e0) = h;
-        }
-      }
-    }
-    // the next tile's X loads overwrite Xs / the ring: everybody must be past this tile's LDS reads, and the epilogue's
-    // loads / stores must not be counted against the next tile's packets
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------------------------------
-// LayerNorm -> linear projection for the narrow (level-0, C = 320) transformer blocks (round 3): Out[M, N] = LN(X)[M, C] . W^T (+ bias),
-// the Q | K | V projections (N = 3C) of the spatial and temporal attention.  As LayerNorm launch + GEMM launch this is the worst-placed pair
-// of the level (profiles/r03_per_shape_hip_events_25step.txt: 76800x960x320 at 92 us = 512 TFLOP/s, + 16 us of LayerNorm): five K steps per
-// tile, so a tile's time is its prologue and its 64 KB of stores, and the 49 MB activation is streamed once by LayerNorm (read + write) and
-// again, once per 128-column tile, by the GEMM.  Here - the fused feed-forward kernel's phase A, kept: the X tile [128 x C] is staged once,
-// normalised in LDS, and ALL N output columns are produced from it in chunks of 128 (weight packets [128 x 64] through the same 3-slot ring);
-// the activation is read once, LayerNorm(x) is never written.  A chunk's outputs are stored AFTER the next packet's barrier and fetch have
-// been issued (the queue then holds, oldest first, the two packets in flight and this wave's four stores - counted, never drained).
-template <int KT>
-__global__ __launch_bounds__(512, 2) void ln_linear_kernel(const LnLinP p) {
-  constexpr int C = KT * 64;
-  constexpr int TILE = 128 * 64;
-  extern __shared__ __attribute__((aligned(16))) f16 smem[];
-  f16* Xs = smem;                              // [KT][128][64]
-  f16* ring = smem + KT * TILE;                // [4][128][64]
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l15 = lane & 15, g = lane >> 4;
-  const int sw = ffswz(l15);
-  const int pc = lane & 7, lrow = lane >> 3;
-  const int nfull = p.N / 128;                 // chunks of 128 output columns ...
-  const bool half = (p.N % 128) != 0;          // ... + one of 64
-  const int nchunk = nfull + (half ? 1 : 0);
-  const int ntiles = (p.M + 127) / 128;
-  const int Q = nchunk * KT;                   // packets per tile
-
-  constexpr unsigned SENT = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)SENT, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (int)((long)p.M * C * 2), 0x00020000);   // rows >= M read zeros
-  const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)p.Out, 0, (int)((long)p.M * p.ldo * 2), 0x00020000);
-  unsigned vo[2], voh, vox;
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {   // LDS row lr holds weight row perm(lr): wave tile 64 columns, 16 contiguous output columns per lane
-    const int lr = (wave * 2 + u) * 8 + lrow;
-    const int part = lr >> 6, rem = lr & 63, jj = rem >> 4, i = rem & 15;
-    const int n = part * 64 + (i >> 2) * 16 + jj * 4 + (i & 3);
-    vo[u] = (unsigned)((n * C + (pc ^ ffswz(lr)) * 8) * 2);
-  }
-  {   // half chunk: 64 weight rows, wave tile 32 columns (8 contiguous output columns per lane)
-    const int lr = wave * 8 + lrow;
-    const int part = lr >> 5, rem = lr & 31, jj = rem >> 4, i = rem & 15;
-    const int n = part * 32 + (i >> 2) * 8 + jj * 4 + (i & 3);
-    voh = (unsigned)((n * C + (pc ^ ffswz(lr)) * 8) * 2);
-  }
-  vox = (unsigned)((lrow * C + 0) * 2);
-  auto is_half = [&](int j) { return half && j == nchunk - 1; };
-  auto issue_packet = [&](int q, int slot) {      // packet q = (chunk j, K tile s)
-    const int j = q / KT, s = q - j * KT;
-    f16* dst = ring + slot * TILE;
-    const int so = (j * 128 * C + s * 64) * 2;
-    if (!is_half(j)) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(dst + (wave * 2 + u) * 8 * 64), 16, (int)vo[u], so, 0, 0);
-    } else {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(dst + wave * 8 * 64), 16, (int)voh, so, 0, 0);
-    }
-  };
-
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int m0 = tile * 128;
-    for (int t = wave; t < KT * 16; t += 8) {
-      const int kt = t >> 4, r = t & 15;
-      const int lr = r * 8 + lrow;
-      const unsigned vx = vox + (unsigned)((r * 8 * C + (pc ^ ffswz(lr)) * 8) * 2);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lptr_t)(Xs + kt * TILE + r * 8 * 64), 16, (int)vx, (m0 * C + kt * 64) * 2, 0, 0);
-    }
-    issue_packet(0, 0);
-    if (Q > 1) issue_packet(1, 1);
-    if (Q > 2) issue_packet(2, 2);
-
-    if (p.ln_g) {
-      // pre-norm on the LDS tile: the fused feed-forward kernel's code (4 threads per token row, exact two-pass statistics in fp32)
-      const int row = tid >> 2, q4 = tid & 3;
-      f16x8 ga[KT][2], be[KT][2];
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          ga[kt][u] = *(const f16x8*)(p.ln_g + kt * 64 + q4 * 16 + u * 8);
-          be[kt][u] = *(const f16x8*)(p.ln_b + kt * 64 + q4 * 16 + u * 8);
-        }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      f16* xr = Xs + row * 64;
-      const int cs[2] = {((q4 * 2) ^ ffswz(row)) * 8, ((q4 * 2 + 1) ^ ffswz(row)) * 8};
-      f16x8 hx[KT][2];
-      float sum = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          hx[kt][u] = *(const f16x8*)(xr + kt * TILE + cs[u]);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) sum += (float)hx[kt][u][e];
-        }
-      sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
-      const float mean = sum / C;
-      float var = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { const float d = (float)hx[kt][u][e] - mean; var += d * d; }
-      var += __shfl_xor(var, 1); var += __shfl_xor(var, 2);
-      const float rstd = rsqrtf(var / C + p.ln_eps);
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          f16x8 y;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) y[e] = (f16)(((float)hx[kt][u][e] - mean) * rstd * (float)ga[kt][u][e] + (float)be[kt][u][e]);
-          *(f16x8*)(xr + kt * TILE + cs[u]) = y;
-        }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-
-    f32x4 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jn = 0; jn < 4; ++jn) acc[i][jn] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // store chunk jd's finished accumulators (+ bias) and clear them; returns the number of stores this wave issued
-    auto flush = [&](int jd) {
-      const bool hf = is_half(jd);
-      const int n0 = jd * 128 + (hf ? wn * 32 + g * 8 : wn * 64 + g * 16);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 32 + i * 16 + l15;
-#pragma unroll
-        for (int e0 = 0; e0 < 16; e0 += 8) {
-          if (hf && e0 >= 8) continue;
-          f16x8 h;
-          if (p.bias) {
-            const f16x8 b = *(const f16x8*)(p.bias + n0 + e0);
-#pragma unroll
-            for (int qq = 0; qq < 8; ++qq) h[qq] = (f16)(acc[i][(e0 + qq) >> 2][(e0 + qq) & 3] + (float)b[qq]);
-          } else {
-#pragma unroll
-            for (int qq = 0; qq < 8; ++qq) h[qq] = (f16)acc[i][(e0 + qq) >> 2][(e0 + qq) & 3];
-          }
-          // buffer store: rows >= M land past num_records and are dropped by the hardware, so every wave issues exactly the same number of
-          // stores - the counted waits below depend on it
-          const unsigned off = m < p.M ? (unsigned)(((long)m * p.ldo + n0 + e0) * 2) : 0xFFFFFFF0u;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, h), rO, (int)off, 0, 0);
-        }
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn) acc[i][jn] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-    };
-
-    int slot = 0;
-    int pend = -1;                       // chunk whose accumulators are complete but not yet stored
-    int behind = 0, since = 99;          // stores of the last flush (2 or 4 per wave) and the iterations since it
-    auto nl_of = [&](int qq) { return qq < Q ? (is_half(qq / KT) ? 1 : 2) : 0; };
-    for (int q = 0; q < Q; ++q) {
-      const int j = q / KT, s = q - j * KT;
-      // packet q must have landed.  Behind it in the (in-order) queue: packets q + 1 and q + 2 (fetched three ahead through a 4-slot ring) and,
-      // for three iterations after a flush, that flush's stores - counted, not drained: a store gets ~4 packet times to be acknowledged
-      // before it stands in front of a packet this wave waits for
-      const int allow = (q == 0) ? 0 : nl_of(q + 1) + nl_of(q + 2) + (since <= 2 ? behind : 0);
-      switch (allow) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-      }
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (q + 3 < Q) issue_packet(q + 3, (slot + 3) & 3);     // the slot of packet q - 1: every wave is past its reads (this barrier)
-      ++since;
-      if (pend >= 0) {
-        // the previous chunk's outputs: issued behind the fetch above so that the next waits can count them instead of draining
-        behind = is_half(pend) ? 2 : 4; since = 0;
-        flush(pend); pend = -1;
-      }
-      const f16* Wt = ring + slot * TILE;
-      slot = (slot + 1) & 3;
-      const bool hf = is_half(j);
-      const f16* Ab = Xs + s * TILE + (wm * 32 + l15) * 64;
-      const f16* Bb = Wt + ((hf ? wn * 32 : wn * 64) + l15) * 64;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int ch = ((kk * 4 + g) ^ sw) * 8;
-        f16x8 bf[4], af[2];
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn)
-          if (!hf || jn < 2) bf[jn] = *(const f16x8*)(Bb + jn * 16 * 64 + ch);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = *(const f16x8*)(Ab + i * 16 * 64 + ch);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int jn = 0; jn < 4; ++jn)
-            if (!hf || jn < 2) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[jn], af[i], acc[i][jn], 0, 0, 0);
-      }
-      if (s == KT - 1) pend = j;
-    }
-    if (pend >= 0) flush(pend);
-    // the next tile's X loads overwrite Xs / the ring: everybody must be past this tile's LDS reads, and the stores drained
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-}
-
-bool ln_linear_supported(int C, int N) { return (C == 64 || C == 128 || C == 192 || C == 256 || C == 320) && N >= 128 && N % 64 == 0; }
-
-template <int KT>
-static void launch_lnlin_t(const LnLinP& p, hipStream_t s) {
-  const size_t lds = (size_t)(KT + 4) * 128 * 64 * sizeof(f16);
-  static bool attr[32] = {};
-  bool& at = attr[ug_dev_slot()];
-  if (!at) { UG_CHECK(hipFuncSetAttribute((const void*)ln_linear_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); at = true; }
-  const int ntiles = (p.M + 127) / 128;
-  const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / lds)));
-  hipLaunchKernelGGL(ln_linear_kernel<KT>, dim3(std::min(ntiles, per_cu * 256)), dim3(512), lds, s, p);
-}
-
-void launch_ln_linear(const LnLinP& p, hipStream_t s) {
-  UG_REQUIRE(ln_linear_supported(p.C, p.N) && p.M > 0 && p.ldo >= p.N && p.ldo % 8 == 0, "ln_linear: C a multiple of 64 up to 320, N a multiple of 64");
-  if (p.ln_g) UG_REQUIRE(p.ln_b != nullptr, "ln_linear: beta missing");
-  switch (p.C / 64) {
-    case 1: launch_lnlin_t<1>(p, s); break;
-    case 2: launch_lnlin_t<2>(p, s); break;
-    case 3: launch_lnlin_t<3>(p, s); break;
-    case 4: launch_lnlin_t<4>(p, s); break;
-    default: launch_lnlin_t<5>(p, s); break;
-  }
-  UG_CHECK(hipGetLastError());
-}
-
-static int g_ff_variant = 2;    // process default (ug_tune_ff, an A/B aid): 2 = cross-tile prefetch, 1 = GEGLU software-pipelined across chunks, 0 = the round-2 kernel
-void ff_fused_set_variant(int v) { g_ff_variant = v; }
-
+// FFusedP::variant (per launch; the engine passes its context's - ug_tune_ff): 0 = the kernel above with the cross-tile prefetch (default), 1 = without
+// it (the round-2 kernel, A/B); UG_EXPERIMENTS builds: 100 + mask = the timing-only ablations of tools/bench_ff.py (WRONG results)
 template <int KT>
 static void launch_ff_t(const FFusedP& p, hipStream_t s) {
   const size_t lds = (size_t)(KT + 3 + 1) * 128 * 64 * sizeof(f16);
@@ -924,13 +369,15 @@ static void launch_ff_t(const FFusedP& p, hipStream_t s) {
   bool& at = attr[ug_dev_slot()];
   if (!at) { UG_CHECK(hipFuncSetAttribute((const void*)ff_fused_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); at = true; }
   const int ntiles = (p.M + 127) / 128;
-  if (g_ff_variant >= 100) {   // ablation timing variants (tools/bench_ff.py ablate): wrong results, KT = 5 only
+  const int variant = p.variant;
+#ifdef UG_EXPERIMENTS
+  if (variant >= 100) {
     if constexpr (KT == 5) {
       auto go = [&](auto kern) {
         UG_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(std::min(ntiles, 256)), dim3(512), lds, s, p);
       };
-      switch (g_ff_variant - 100) {
+      switch (variant - 100) {
         case 1: go(ff_fused_kernel<5, 1>); break;  case 2: go(ff_fused_kernel<5, 2>); break;   case 4: go(ff_fused_kernel<5, 4>); break;
         case 8: go(ff_fused_kernel<5, 8>); break;  case 16: go(ff_fused_kernel<5, 16>); break; case 12: go(ff_fused_kernel<5, 12>); break;
         case 3: go(ff_fused_kernel<5, 3>); break;  case 14: go(ff_fused_kernel<5, 14>); break; case 30: go(ff_fused_kernel<5, 30>); break;
@@ -940,7 +387,8 @@ static void launch_ff_t(const FFusedP& p, hipStream_t s) {
       return;
     }
   }
-  if (g_ff_variant == 2) {
+#endif
+  if (variant == 0) {
     if constexpr (KT >= 2 && (KT * 64 + 127) / 128 >= 2) {
       static bool attrx[32] = {};
       bool& atx = attrx[ug_dev_slot()];
@@ -949,14 +397,6 @@ static void launch_ff_t(const FFusedP& p, hipStream_t s) {
       hipLaunchKernelGGL((ff_fused_kernel<KT, 0, true>), dim3(std::min(ntiles, per_cu_x * 256)), dim3(512), lds, s, p);
       return;
     }
-  }
-  if (g_ff_variant == 1) {
-    static bool attrp[32] = {};
-    bool& atp = attrp[ug_dev_slot()];
-    if (!atp) { UG_CHECK(hipFuncSetAttribute((const void*)ff_fused_pipe_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); atp = true; }
-    const int per_cu_p = std::max(1, std::min(2, (int)((160 * 1024) / lds)));
-    hipLaunchKernelGGL(ff_fused_pipe_kernel<KT>, dim3(std::min(ntiles, per_cu_p * 256)), dim3(512), lds, s, p);
-    return;
   }
   const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / lds)));
   const int grid = std::min(ntiles, per_cu * 256);

@@ -670,11 +670,12 @@ static bool gemm_can_bufa(const GemmP& p, int BK, bool packed) {
 // publishes step i+1 and frees slot i % 3.  Only producers ever have loads in flight in the K loop, so the epilogue's
 // global traffic (consumers) needs no drain logic.  LDS image, W row permutation, MFMA chain order and epilogue are those
 // of gemm_kernel: outputs are bit-identical.
-template <int BM, int BN, int WMW, int WNW, bool CONV, int NST = 3, bool XS = false>
-__global__ __launch_bounds__((WMW * WNW + 4) * 64, (WMW * WNW == 8 ? 3 : 2)) void gemm_ws_kernel(const GemmP p) {
+template <int BM, int BN, int WMW, int WNW, bool CONV>
+__global__ __launch_bounds__((WMW * WNW + 4) * 64, 3) void gemm_ws_kernel(const GemmP p) {
+  constexpr int NST = 3;
   constexpr int BK = 64;
-  static_assert(BN % 32 == 0 && (BM == 256 || BM == 192) && NST * (BM + BN) * BK * 2 <= 160 * 1024 && NST >= 3 && NST <= 4, "ring of NST BM x BN x 64 slots must fit 160 KiB; BM / 32 A pieces per fetch wave");
-  static_assert(WMW * WNW == 8 || WMW * WNW == 4, "eight consumer waves (three waves per SIMD with the fetch wave) or four with twice the wave tile (two per SIMD, <= 256 VGPRs)");
+  static_assert(BN % 32 == 0 && (BM == 256 || BM == 192) && NST * (BM + BN) * BK * 2 <= 160 * 1024, "ring of three BM x BN x 64 slots must fit 160 KiB; BM / 32 A pieces per fetch wave");
+  static_assert(WMW * WNW == 8, "eight consumer waves (three waves per SIMD with the fetch wave)");
   constexpr int NCW = WMW * WNW;
   constexpr unsigned SENT = 0x80000000u;
   constexpr int WTM = BM / WMW, WTN = BN / WNW;
@@ -808,9 +809,7 @@ __global__ __launch_bounds__((WMW * WNW + 4) * 64, (WMW * WNW == 8 ? 3 : 2)) voi
     // prologue: steps 0 .. NST-2; step 0 must have landed before the first barrier
     if (total_it > 0) issue();
     if (total_it > 1) issue();
-    if (NST == 4 && total_it > 2) issue();
-    if (NST == 4 && total_it > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LA + LB)) : "memory");
-    else if (total_it > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA + LB) : "memory");
+    if (total_it > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA + LB) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #ifdef UG_GEMM_TRACE
@@ -823,8 +822,6 @@ __global__ __launch_bounds__((WMW * WNW + 4) * 64, (WMW * WNW == 8 ? 3 : 2)) voi
         issue();                                                            // step fi+NST-1 -> the slot the consumers left before the previous barrier
         UG_STAMP(1);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (LA + LB)) : "memory");       // step fi+1 has landed (NST-2 younger steps may be in flight)
-      } else if (NST == 4 && fi + 2 < total_it) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA + LB) : "memory");       // ring draining: only step fi+2 is younger than fi+1
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -857,64 +854,6 @@ __global__ __launch_bounds__((WMW * WNW + 4) * 64, (WMW * WNW == 8 ? 3 : 2)) voi
   const bool traced = p.trace && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (wave == 0 || wave == 4);
   unsigned* tr_lds = (unsigned*)(smem + NST * STAGE) + (wave == 4 ? 24 * 5 : 0);
 #endif
-  if (XS) {
-    // Cross-step form (round 3).  The K-step traces of the form below (tools/gemm_trace.py ... 63: ~1700 cycles per step on the 192 x 128 tile
-    // against 782 of MFMAs for the two consumer waves of a SIMD) show what is exposed: every step starts with the latency of its first
-    // fragment reads and ends with the barrier hand-over, and both consumer waves of a SIMD sit in those gaps together.  Here a step's two
-    // 32-deep halves use two fragment sets that are refilled ACROSS the step boundary: while the MFMAs of half 0 run, half 1 of the same slot
-    // is read; then the barrier (all of this slot is in registers: it is free, and the next step is published), the reads of half 0 of the NEXT
-    // slot are issued, and the MFMAs of half 1 run over them.  Same registers (two half-sets = one full set), same barrier count, same MFMA
-    // order (bit-identical outputs); the first reads of a tile are the only exposed ones.
-    f16x8 a0[MT], b0[NT], a1[MT], b1[NT];
-    auto rd = [&](int slot, int kk, f16x8 (&af)[MT], f16x8 (&bf)[NT]) {
-      const f16* Ab = smem + slot * STAGE + (wm * WTM + l15) * BK;
-      const f16* Bb = smem + slot * STAGE + BM * BK + (wn * WTN + l15) * BK;
-      const int ch = ((kk * 4 + g) ^ sw) * 8;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) bf[j] = *(const f16x8*)(Bb + j * 16 * BK + ch);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *(const f16x8*)(Ab + i * 16 * BK + ch);
-    };
-    auto mm = [&](const f16x8 (&af)[MT], const f16x8 (&bf)[NT]) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-    };
-    if (total_it > 0) rd(0, 0, a0, b0);
-    for (int fi = 0; fi < total_it; ++fi) {
-      UG_STAMP(0);
-      rd(cp_slot, 1, a1, b1);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(a0, b0);
-      __builtin_amdgcn_sched_barrier(0);
-      UG_STAMP(1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // both halves of this slot are in registers: it is handed back
-      UG_STAMP(2);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      UG_STAMP(3);
-      if (++cp_slot == NST) cp_slot = 0;
-      const bool tile_end = ++cp_ks == nk;
-      if (!tile_end && fi + 1 < total_it) rd(cp_slot, 0, a0, b0);   // next step's first half, fetched under the MFMAs of this step's second half
-      __builtin_amdgcn_sched_barrier(0);
-      mm(a1, b1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (tile_end) {
-        cp_ks = 0;
-        const int tile = wslot + (cp_ti++) * nwg;
-        { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn); tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
-        if (fi + 1 < total_it) rd(cp_slot, 0, a0, b0);    // (after the epilogue: its registers are the tight spot of this kernel)
-      }
-#ifdef UG_GEMM_TRACE
-      if (traced && fi == 40) {
-        __builtin_amdgcn_s_waitcnt(0);
-        for (int i = lane; i < 24 * 5; i += 64) ((unsigned*)p.trace)[(wave == 4 ? 24 * 5 : 0) + i] = tr_lds[i];
-      }
-#endif
-    }
-    return;
-  }
   for (int fi = 0; fi < total_it; ++fi) {
     UG_STAMP(0);
     const f16* Ab = smem + cp_slot * STAGE + (wm * WTM + l15) * BK;
@@ -967,19 +906,19 @@ __global__ __launch_bounds__((WMW * WNW + 4) * 64, (WMW * WNW == 8 ? 3 : 2)) voi
   }
 }
 
-template <int BN, int WMW, int WNW, int BM = 256, int NST = 3, bool XS = false>
+template <int BN, int WMW, int WNW, int BM = 256>
 static void launch_ws(const GemmP& p, int batch, hipStream_t s) {
   const int ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
 #ifdef UG_GEMM_TRACE
-  const size_t lds = NST * (BM + BN) * 64 * sizeof(f16) + 2048;
+  const size_t lds = 3 * (BM + BN) * 64 * sizeof(f16) + 2048;
 #else
-  const size_t lds = NST * (BM + BN) * 64 * sizeof(f16);
+  const size_t lds = 3 * (BM + BN) * 64 * sizeof(f16);
 #endif
   static bool attr[32] = {};
   bool& at = attr[ug_dev_slot()];
   if (!at) {
-    UG_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<BM, BN, WMW, WNW, true, NST, XS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    UG_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<BM, BN, WMW, WNW, false, NST, XS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    UG_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<BM, BN, WMW, WNW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    UG_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<BM, BN, WMW, WNW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     at = true;
   }
   const int split = p.splitk > 1 ? p.splitk : 1;
@@ -987,8 +926,8 @@ static void launch_ws(const GemmP& p, int batch, hipStream_t s) {
   gx = (gx / 8) * 8;
   gx = std::min(gx, ntiles);
   dim3 grid(gx, split, batch);
-  if (p.conv) hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, WMW, WNW, true, NST, XS>), grid, dim3((WMW * WNW + 4) * 64), lds, s, p);
-  else hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, WMW, WNW, false, NST, XS>), grid, dim3((WMW * WNW + 4) * 64), lds, s, p);
+  if (p.conv) hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, WMW, WNW, true>), grid, dim3((WMW * WNW + 4) * 64), lds, s, p);
+  else hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, WMW, WNW, false>), grid, dim3((WMW * WNW + 4) * 64), lds, s, p);
 }
 
 template <int BM, int BN, int NST, int WMW, int WNW>
@@ -1137,16 +1076,8 @@ static void launch_cfg(int cfg, const GemmP& p, int batch, hipStream_t s) {
     // tiles for 256 CUs (fill 0.98) where 256 rows give 375 / 190 (fill 0.73)
     case 61: launch_mode<192, 128, 64, 3, 2, 4>(p, batch, s); break;  // 120 KiB, 8 waves, wave tile 96x32
     case 62: launch_mode<192, 128, 64, 3, 4, 2>(p, batch, s); break;  // 120 KiB, 8 waves, wave tile 48x64 (GEGLU-capable)
-    // Round-3 experiments on the 192 x 128 producer / consumer tile, kept selectable (all bit-identical, all within +-1 % of the default form - DESIGN 7c):
-    // knob 65536 = FOUR 40 KiB ring slots (exactly the CU's 160 KiB: three K-steps of operands in flight instead of two); knob 131072 = four slots + the
-    // cross-step consumer loop (fragment halves refilled across the step boundary, barrier in mid-step); cfg 65 / 66 = FOUR consumer waves with twice the
-    // wave tile (96 x 64 / 128 x 64: 80 / 96 KiB of fragment reads per K-step instead of 128 / 112) - 2 - 30 % slower.
-    case 65: if (gemm_can_bufa(p, 64, true)) launch_ws<128, 2, 2, 192, 4, true>(p, batch, s); else launch_mode<192, 128, 64, 3, 4, 2>(p, batch, s); break;
-    case 66: if (gemm_can_bufa(p, 64, true)) launch_ws<128, 2, 2, 256, 3, true>(p, batch, s); else launch_mode<256, 128, 64, 3, 4, 2>(p, batch, s); break;
-    case 63: if (gemm_can_bufa(p, 64, true)) { if (!ring3 && (p.tune_knobs & 131072)) launch_ws<128, 2, 4, 192, 4, true>(p, batch, s); else if (!ring3 && (p.tune_knobs & 65536)) launch_ws<128, 2, 4, 192, 4>(p, batch, s); else launch_ws<128, 2, 4, 192>(p, batch, s); }
-             else launch_mode<192, 128, 64, 3, 2, 4>(p, batch, s); break;   // producer / consumer form of 61
-    case 64: if (gemm_can_bufa(p, 64, true)) { if (!ring3 && (p.tune_knobs & 131072)) launch_ws<128, 4, 2, 192, 4, true>(p, batch, s); else if (!ring3 && (p.tune_knobs & 65536)) launch_ws<128, 4, 2, 192, 4>(p, batch, s); else launch_ws<128, 4, 2, 192>(p, batch, s); }
-             else launch_mode<192, 128, 64, 3, 4, 2>(p, batch, s); break;   // ... of 62
+    case 63: if (gemm_can_bufa(p, 64, true)) launch_ws<128, 2, 4, 192>(p, batch, s); else launch_mode<192, 128, 64, 3, 2, 4>(p, batch, s); break;   // producer / consumer form of 61
+    case 64: if (gemm_can_bufa(p, 64, true)) launch_ws<128, 4, 2, 192>(p, batch, s); else launch_mode<192, 128, 64, 3, 4, 2>(p, batch, s); break;   // ... of 62
     // halo-staged 3x3 convolutions (kernels/conv_halo.hip): the activation halo of a 64-channel chunk is fetched once for its nine taps
     case 70: UG_REQUIRE(conv_halo_supported(p, batch, 256, 160), "config 70: not a halo-stageable convolution"); launch_conv_halo(p, 256, 160, s); break;
     case 71: UG_REQUIRE(conv_halo_supported(p, batch, 256, 128), "config 71: not a halo-stageable convolution"); launch_conv_halo(p, 256, 128, s); break;
@@ -1365,7 +1296,7 @@ static int pick_group_m(const GemmP& p, int cfg, int batch, int split) {
     case 14: case 34: bm = 256; bn = 64; percu = 2; break;
     case 15: case 35: bm = 256; bn = 256; break;
     case 60: case 70: bm = 256; bn = 160; break;
-    case 61: case 62: case 63: case 64: case 65: case 72: bm = 192; bn = 128; break;
+    case 61: case 62: case 63: case 64: case 72: bm = 192; bn = 128; break;
     case 73: bm = 192; bn = 160; break;
     default: break;                                                    // 4, 8, 19, 39, 54, 59, 71: 256 x 128
   }
@@ -1397,7 +1328,7 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
   }
   int cfg = p.cfg_p1 - 1, split = p.splitk;
   if (cfg < 0 || split < 1) { int c2, s2; gemm_plan(p, batch, &c2, &s2); if (cfg < 0) cfg = c2; if (split < 1) split = s2; }
-  if (p.flags & UG_F_GEGLU) UG_REQUIRE(cfg == 0 || cfg == 4 || cfg == 8 || cfg == 15 || cfg == 35 || cfg == 54 || cfg == 62 || cfg == 64 || cfg == 65 || cfg == 66, "GEGLU needs a 64-column wave tile");
+  if (p.flags & UG_F_GEGLU) UG_REQUIRE(cfg == 0 || cfg == 4 || cfg == 8 || cfg == 15 || cfg == 35 || cfg == 54 || cfg == 62 || cfg == 64, "GEGLU needs a 64-column wave tile");
   p.splitk = split;
   // Row split for the 3x3 convolutions onto 320 columns (level 0 of the clip): 128-wide tiles waste a sixth of their columns there (320 =
   // 2.5 x 128) and the 256x160 producer / consumer tile (config 60), which wastes none, leaves 88 of its 600 tiles for a third round.
@@ -1450,7 +1381,7 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
   p.tm_T = p.tm_nb = 0;
   if (p.conv && p.kt > 1 && p.T > 1 && batch == 1 && !(p.tune_knobs & 256)) {   // knob 256: frame-major M walk for temporal convs (A/B)
     int bm = 256;
-    switch (cfg) { case 0: case 1: case 3: bm = 128; break; case 12: bm = 64; break; case 61: case 62: case 63: case 64: case 65: bm = 192; break; default: break; }
+    switch (cfg) { case 0: case 1: case 3: bm = 128; break; case 12: bm = 64; break; case 61: case 62: case 63: case 64: bm = 192; break; default: break; }
     const long hw = (long)p.Ho * p.Wo;
     if (hw % bm == 0 && hw / bm >= 1) { p.tm_T = p.T; p.tm_nb = (int)(hw / bm); }
   }

@@ -431,189 +431,6 @@ static inline int gn_slab_plan(const GroupNormP& p, int& vmax, bool per_frame = 
   return 0;
 }
 
-// ------------------------------------------------------------------------------------------
-// Round 3: ONE launch, ONE read.  A [T*HW, C] activation of the UNet (<= ~50 MB at level 0) fits in the register files of the chip, so a
-// workgroup keeps its rows in registers across the statistics hand-off instead of reading them a second time:
-//   1. load rows -> registers (<= GNF_VPT 8-channel vectors per thread), per-group partial sums -> global (write-through stores);
-//   2. ticket per frame: the LAST workgroup of a frame to arrive combines that frame's partials in fp64 (fixed order: deterministic) and
-//      publishes the frame's totals (temporal variant: the last FRAME to finish pools the frames' totals);
-//   3. every workgroup waits for its frame's (or the pooled) totals, then normalises its registers and stores.
-// 98 instead of 147 MB of traffic on a 49 MB tensor, one launch instead of three.  What killed round 1's one-launch attempt (agent-scope
-// release / acquire fences flush and invalidate the L2: 162 ms of GroupNorm per clip) is avoided by publishing ONLY the tiny partials /
-// totals, with system-scope (sc0 sc1) stores and loads + s_waitcnt + a device-scope ticket - MI355X_MICROARCH.md's "valid forms": no fence,
-// no bulk data crosses workgroups.  Residency: a frame's workgroups are contiguous in dispatch order and never wait for a later frame, so
-// per-frame statistics cannot deadlock whatever the grid size; the pooled (temporal) variant needs the whole grid resident and is only
-// chosen for <= GNF_MAX_RESIDENT workgroups (5 per CU at <= 96 VGPRs).  Waits are bounded: a hand-off that does not arrive within ~1 s sets
-// GnSync::err (checked by the engine at the end of the pipeline call) instead of hanging the GPU.
-// ------------------------------------------------------------------------------------------
-#define GNF_VPT 12
-#define GNF_MAX_RESIDENT 1152
-struct GnSync { unsigned ticket[128]; unsigned done[128]; unsigned gticket, gdone, err, pad; };
-
-__device__ __forceinline__ void st_sys(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ float ld_sys(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void st_sys(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ double ld_sys(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void st_sys(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ unsigned ld_sys(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-
-__global__ __launch_bounds__(GN_THREADS, 5) void gn_fused(const GroupNormP p, int nchunk, int rows_per_chunk, GnSync* sy, unsigned tag,
-                                                            float* part, double* tot) {
-  extern __shared__ float red[];   // [rpi][C][2]; reused for mean / rstd
-  __shared__ int sh_last;
-  const int C = p.C0 + p.C1, G = p.G, cpg = C / G;
-  const GnGeom gg = gn_geom(C);                  // vpt == 1 (C <= 2048): tpr threads per row, rpi rows per iteration
-  const int t = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-  const int rsub = tid / gg.tpr, v0 = tid - rsub * gg.tpr;
-  const bool active = rsub < gg.rpi;
-  const int r0 = chunk * rows_per_chunk, r1 = min(r0 + rows_per_chunk, p.HW);
-  const int c = v0 * 8;
-  // ---- 1. rows -> registers, per-channel partial sums
-  f16x8 x[GNF_VPT];
-  float s[8], q[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
-  if (active) {
-#pragma unroll
-    for (int k = 0; k < GNF_VPT; ++k) {
-      const int r = r0 + rsub + k * gg.rpi;
-      if (r < r1) x[k] = gn_load(p, (long)t * p.HW + r, c);
-    }
-#pragma unroll
-    for (int k = 0; k < GNF_VPT; ++k) {
-      const int r = r0 + rsub + k * gg.rpi;
-      if (r < r1) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float f = (float)x[k][e]; s[e] += f; q[e] += f * f; }
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      red[((long)rsub * C + c + e) * 2 + 0] = s[e];
-      red[((long)rsub * C + c + e) * 2 + 1] = q[e];
-    }
-  }
-  __syncthreads();
-  for (int g = tid; g < G; g += GN_THREADS) {
-    float a = 0.f, b = 0.f;
-    for (int rs = 0; rs < gg.rpi; ++rs)
-      for (int cc = g * cpg; cc < (g + 1) * cpg; ++cc) { a += red[((long)rs * C + cc) * 2 + 0]; b += red[((long)rs * C + cc) * 2 + 1]; }
-    float* dst = part + (((long)t * nchunk + chunk) * G + g) * 2;
-    st_sys(dst, a); st_sys(dst + 1, b);
-  }
-  // ---- 2. ticket: every partial of this workgroup is acknowledged before it counts as arrived
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) sh_last = (atomicAdd(&sy->ticket[t], 1u) == (unsigned)(nchunk - 1)) ? 1 : 0;
-  __syncthreads();
-  __shared__ double sda[GN_THREADS], sdb[GN_THREADS];
-  if (sh_last) {
-    // last workgroup of frame t: the frame's totals.  NT / G threads per group, each summing every SUB-th chunk partial in fp64 (all of a
-    // thread's uncached loads are issued before the first is used), then a fixed-order combine of the SUB sub-sums: deterministic
-    const int SUB = GN_THREADS / G, g = tid % G, sub = tid / G;
-    {
-      double a = 0.0, b = 0.0;
-      const float* src = part + ((long)t * nchunk * G + g) * 2;
-      for (int ch0 = sub; ch0 < nchunk; ch0 += 4 * SUB) {
-        float va[4], vb[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int ch = ch0 + u * SUB;
-          va[u] = ch < nchunk ? ld_sys(src + (long)ch * G * 2) : 0.f; vb[u] = ch < nchunk ? ld_sys(src + (long)ch * G * 2 + 1) : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { a += (double)va[u]; b += (double)vb[u]; }
-      }
-      sda[tid] = a; sdb[tid] = b;
-    }
-    __syncthreads();
-    if (tid < G) {
-      double a = sda[tid], b = sdb[tid];
-      for (int s2 = 1; s2 < SUB; ++s2) { a += sda[tid + s2 * G]; b += sdb[tid + s2 * G]; }
-      st_sys(tot + ((long)t * G + tid) * 2, a); st_sys(tot + ((long)t * G + tid) * 2 + 1, b);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (!p.temporal) {
-      if (tid == 0) { st_sys(&sy->ticket[t], 0u); st_sys(&sy->done[t], tag); }
-    } else {
-      if (tid == 0) { st_sys(&sy->ticket[t], 0u); sh_last = (atomicAdd(&sy->gticket, 1u) == (unsigned)(p.T - 1)) ? 2 : 1; }
-      __syncthreads();
-      if (sh_last == 2) {   // last frame: pool the frames' totals into slot T (SUB threads per group over the frames, fixed-order combine)
-        double a = 0.0, b = 0.0;
-        for (int tt = sub; tt < p.T; tt += SUB) { a += ld_sys(tot + ((long)tt * G + g) * 2); b += ld_sys(tot + ((long)tt * G + g) * 2 + 1); }
-        sda[tid] = a; sdb[tid] = b;
-        __syncthreads();
-        if (tid < G) {
-          a = sda[tid]; b = sdb[tid];
-          for (int s2 = 1; s2 < SUB; ++s2) { a += sda[tid + s2 * G]; b += sdb[tid + s2 * G]; }
-          st_sys(tot + ((long)p.T * G + tid) * 2, a); st_sys(tot + ((long)p.T * G + tid) * 2 + 1, b);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) { st_sys(&sy->gticket, 0u); st_sys(&sy->gdone, tag); }
-      }
-    }
-  }
-  // ---- 3. wait (bounded) for the totals this workgroup needs
-  if (tid == 0) {
-    const unsigned* flag = p.temporal ? &sy->gdone : &sy->done[t];
-    long spins = 0;
-    while (ld_sys(flag) != tag) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > 1500000L) { st_sys(&sy->err, 1u); break; }     // ~1-2 s: report instead of hanging the GPU
-    }
-  }
-  __syncthreads();
-  float* mr = red;     // [G][2]
-  for (int g = tid; g < G; g += GN_THREADS) {
-    const long slot = p.temporal ? p.T : t;
-    const double a = ld_sys(tot + (slot * G + g) * 2), b = ld_sys(tot + (slot * G + g) * 2 + 1);
-    const double n = (double)cpg * p.HW * (p.temporal ? p.T : 1);
-    const double mean = a / n;
-    double var = b / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    mr[2 * g] = (float)mean; mr[2 * g + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
-  }
-  __syncthreads();
-  if (!active) return;
-  float ca[8], cb[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int cc = c + e, g = cc / cpg;
-    const float ga = p.gamma ? (float)p.gamma[cc] : 1.f, be = p.beta ? (float)p.beta[cc] : 0.f;
-    ca[e] = mr[2 * g + 1] * ga; cb[e] = be - mr[2 * g] * ca[e];
-  }
-#pragma unroll
-  for (int k = 0; k < GNF_VPT; ++k) {
-    const int r = r0 + rsub + k * gg.rpi;
-    if (r < r1) {
-      f16x8 y;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float f = (float)x[k][e] * ca[e] + cb[e];
-        if (p.silu) f = silu_f(f);
-        y[e] = (f16)f;
-      }
-      *(f16x8*)(p.Y + ((long)t * p.HW + r) * C + c) = y;
-    }
-  }
-}
-
-// chunking of the one-launch kernel: rows per chunk bounded by what a workgroup holds in registers; false = not eligible
-static inline bool gn_fused_plan(const GroupNormP& p, int& nchunk, int& rpc) {
-  const int C = p.C0 + p.C1;
-  if (!p.sync || C % 8 || C / 8 > GN_THREADS || p.T > 128) return false;
-  const GnGeom gg = gn_geom(C);
-  const int cap = GNF_VPT * gg.rpi;                       // rows a workgroup can keep
-  const int want = std::max(1, 1024 / p.T);               // chunks per frame for ~1024 workgroups
-  rpc = std::min(cap, std::max(gg.rpi, cdiv(p.HW, want)));
-  nchunk = cdiv(p.HW, rpc);
-  if (nchunk > 128) return false;                         // (the VAE's 196608-pixel frames: stay on the streaming three-launch scheme)
-  if (p.temporal && (long)p.T * nchunk > GNF_MAX_RESIDENT) return false;
-  return true;
-}
-
 static inline void gn_chunks2(int T, int HW, int C, int& nchunk, int& rpc) {
   const GnGeom gg = gn_geom(C);
   static const int total_want = getenv("UG_GN_WANT") ? atoi(getenv("UG_GN_WANT")) : 1024;   // A/B aid
@@ -625,19 +442,14 @@ static inline void gn_chunks2(int T, int HW, int C, int& nchunk, int& rpc) {
   if (nchunk > 128) { nchunk = 128; rpc = cdiv(HW, nchunk); nchunk = cdiv(HW, rpc); }
 }
 
-size_t groupnorm_sync_bytes() { return sizeof(GnSync); }
-
 size_t groupnorm_ws_floats(int T, int HW, int C, int G) {
   int nchunk, rpc;
   gn_chunks2(T, HW, C, nchunk, rpc);
-  // three-launch scheme: chunk partials + per-(frame, channel) scale / shift; one-launch scheme: <= 128 chunk partials per frame + (T + 1) x G
-  // fp64 totals (8-byte aligned: the partial area is an even number of floats)
-  const size_t three = (size_t)T * nchunk * G * 2 + (size_t)T * C * 2;
-  const size_t one = (size_t)T * 128 * G * 2 + (size_t)(T + 1) * G * 2 * 2 + 2;
-  return three > one ? three : one;
+  // three-launch scheme: chunk partials + per-(frame, channel) scale / shift (the per-frame slab scheme needs T x G x 2 of them)
+  return (size_t)T * nchunk * G * 2 + (size_t)T * C * 2;
 }
 
-// Launch scheme (p.mode 0 = pick, 1 / 2 / 3 / 4 force; tools/bench_groupnorm.py, profiles/r01_groupnorm_variants.txt):
+// Launch scheme (p.mode 0 = pick, 1 / 2 / 4 / 6 force; tools/bench_groupnorm.py, profiles/r01_groupnorm_variants.txt):
 //   4: gn_slab, one workgroup per (group, frame) with the slab in registers (round 3; replaces 2 wherever it fits)
 //   6: pooled statistics from per-frame slabs, two launches (round 4).  Round 4 also re-measured gn_apply combining the chunk partials itself (no
 //      gn_finalize launch, first loads issued before the combine): 41.2 vs 40.3 us isolated, +3 us on the one-frame StableNormal tensors, +-0 in the clip - removed.
@@ -655,8 +467,6 @@ void launch_groupnorm(const GroupNormP& p, hipStream_t s) {
   const long slab = (long)p.HW * cpg * (p.temporal ? p.T : 1);
   const bool small_ok = !p.temporal && cpg % 4 == 0 && p.C0 % 4 == 0 && p.gamma && p.beta;
   int mode = p.mode;
-  int fch = 0, frpc = 0;
-  const bool fused_ok = gn_fused_plan(p, fch, frpc);
   int svmax = 0, tvmax = 0;
   const int snt = gn_slab_plan(p, svmax);
   const int tnt = p.temporal ? gn_slab_plan(p, tvmax, true) : 0;   // per-frame slabs of the pooled variant (mode 6)
@@ -671,23 +481,17 @@ void launch_groupnorm(const GroupNormP& p, hipStream_t s) {
     if (small_ok && slab <= 16384 && narrow_ok) mode = (snt && !noslab) ? 4 : 2;
     else if (!p.temporal && snt && svmax <= 16 && narrow_ok && p.G * p.T >= 256 && !noslab) mode = 4;
     else if (p.temporal && tnt && tvmax <= 16 && p.HW <= 256 && p.G * p.T >= 256 && !not2) mode = 6;
-    else mode = fused_ok ? 3 : 1;
+    else mode = 1;
   }
   if (mode == 4 && !snt) mode = p.temporal ? 1 : 2;
   if (mode == 2 && !small_ok) mode = 1;
-  if (mode == 3 && !fused_ok) mode = 1;
+  if (mode == 3) mode = 1;   // (3 was round 3's one-launch ticket scheme: slower than three launches everywhere, removed in round 4)
   if (mode == 6 && !tnt) mode = 1;
   if (mode == 4) {
     gn_slab_launch<0>(p, snt, svmax, dim3(p.G, p.temporal ? 1 : p.T), s);
   } else if (mode == 6) {
     gn_slab_launch<1>(p, tnt, tvmax, dim3(p.G, p.T), s);
     gn_slab_launch<2>(p, tnt, tvmax, dim3(p.G, p.T), s);
-  } else if (mode == 3) {
-    const GnGeom gg = gn_geom(C);
-    const size_t lds = std::max((size_t)gg.rpi * C * 2 * sizeof(float), (size_t)p.G * 2 * sizeof(float));
-    float* part = p.ws;
-    double* tot = (double*)(p.ws + (((size_t)p.T * fch * p.G * 2 + 1) & ~(size_t)1));
-    hipLaunchKernelGGL(gn_fused, dim3(fch, p.T), dim3(GN_THREADS), lds, s, p, fch, frpc, (GnSync*)p.sync, p.tag, part, tot);
   } else if (mode == 2) {
     hipLaunchKernelGGL(gn_small, dim3(p.G, p.T), dim3(256), 0, s, p);
   } else {
