@@ -200,8 +200,8 @@ void launch_clip_patchify(const f16* video_m11, f16* patches, int T, int H, int 
                           int P, int Kpad, hipStream_t s, int imagenet_norm = 0);   // 0: CLIP mean/std, 1: ImageNet mean/std (DINOv2)
 void launch_scale_rows(f16* w, const f16* gamma, int N, int K, hipStream_t s);     // w[n][:] *= gamma[n] (LayerScale folded into a projection)
 void launch_add_grid_nearest(f16* x, const f16* grid, int B, int h, int w, int g, int C, hipStream_t s);   // x[b,y,x,:] += grid[b, y*g/h, x*g/w, :]
-void launch_sn_normals_out(const f16* dec, int ldd, float* out, long pixels, hipStream_t s);
-void launch_resize_bilinear_aa(const float* in, float* out, int B, int Hi, int Wi, int Ho, int Wo, int C, int normalise, hipStream_t s);   // torch antialias bilinear   // clip to [-1,1], L2-normalise -> f32 [pixels,3]
+void launch_sn_normals_out(const f16* dec, int ldd, float* out, long pixels, hipStream_t s);   // clip to [-1,1], L2-normalise -> f32 [pixels,3]
+void launch_resize_bilinear_aa(const float* in, float* out, int B, int Hi, int Wi, int Ho, int Wo, int C, int normalise, hipStream_t s);   // torch antialias bilinear; normalise: re-normalise the channel vector
 void launch_init_latents2(const float* noise, f16* lat, float sigma0, int T, long hw, hipStream_t s);
 void launch_silu_f16(const f16* in, f16* out, long n, hipStream_t s);
 void launch_clip_assemble(const f16* patches, const f16* cls, const f16* pos, f16* tok, int T, int np, int d,

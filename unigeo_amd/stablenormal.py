@@ -76,7 +76,10 @@ class StableNormalPredictorHIP:
         self.prediction_type = prediction_type
         # the DINO tower + DINO ControlNet run on a second HIP stream beside the YOSO estimate (one image's kernels fill a fraction of the chip);
         # bit-identical to the in-order schedule (tests/test_stablenormal_gpu.py)
-        engine.set_concurrency(2)
+        try:
+            engine.set_concurrency(2)
+        except AttributeError:      # an older library selected through UG_LIB_PATH (tools/ab A/B runs) may not export it: in-order schedule
+            pass
         self.prompt_embeds = np.ascontiguousarray(prompt_embeds, dtype=np.float32)
         if self.prompt_embeds.shape != (77, cfgs[0].cross_attention_dim):
             raise ValueError(f"prompt_embeds must be [77, {cfgs[0].cross_attention_dim}]")
