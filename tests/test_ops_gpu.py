@@ -479,7 +479,7 @@ def test_ff_fused_with_in_kernel_layernorm(engine, M, C, rpv):
 
 @pytest.mark.parametrize("T,H,W,C0,C1,O", [
     (1, 16, 16, 64, 0, 128),        # one 16 x 16 tile
-    (2, 48, 64, 128, 0, 320),       # 320 columns: level-0 geometry (planner keeps im2col unless knob 32768)
+    (2, 48, 64, 128, 0, 320),       # 320 columns: level-0 geometry (three 128-column tiles, the third half empty)
     (2, 24, 32, 128, 64, 160),      # two sources, 192-pixel tiles
     (2, 32, 48, 64, 0, 128),        # width 48: three 16-pixel tile columns
     (1, 32, 32, 192, 0, 256),       # three 64-channel chunks
@@ -491,7 +491,7 @@ def test_ff_fused_with_in_kernel_layernorm(engine, M, C, rpv):
 def test_conv_halo_bitwise_and_reference(engine, T, H, W, C0, C1, O):
     """Halo-staged 3x3 convolution (kernels/conv_halo.hip: the activation halo of a 64-channel chunk is fetched once for its nine taps) against the
     im2col GEMM it replaces (knob 16384 = halo off): same products, same K order -> bit-identical; the im2col result itself against torch.
-    Knob 32768 also takes the 256 x 160 tile (level-0 widths), which the planner leaves on im2col because it measured slower."""
+    Knob 32768 keeps the 320-column (level-0) convolutions on the row-split im2col pair they ran on until round 3."""
     rng = np.random.default_rng(T * H * W + C0 + O)
     x0 = rnd(rng, T, H, W, C0)
     x1 = rnd(rng, T, H, W, C1) if C1 else None
@@ -506,7 +506,7 @@ def test_conv_halo_bitwise_and_reference(engine, T, H, W, C0, C1, O):
     finally:
         engine.tune_force(-100 - 0, -1)
     assert np.array_equal(got, ref), f"halo vs im2col: max diff {np.abs(got - ref).max()}"
-    assert np.array_equal(got2, ref), f"halo (256 x 160 allowed) vs im2col: max diff {np.abs(got2 - ref).max()}"
+    assert np.array_equal(got2, ref), f"knob 32768 vs im2col: max diff {np.abs(got2 - ref).max()}"
     if T * H * W <= 8192:
         xx = np.concatenate([x0, x1], -1) if C1 else x0
         assert_close(ref, conv_ref(xx, w, b), TOL, "im2col reference itself")
@@ -515,8 +515,8 @@ def test_conv_halo_bitwise_and_reference(engine, T, H, W, C0, C1, O):
 @pytest.mark.parametrize("C1", [0, 320])
 def test_conv_row_split_bitwise_full_size(engine, C1):
     """3x3 convolution onto 320 channels at the clip's level-0 size (25 x 48 x 64 = 76800 rows): launch_gemm runs the rows of the whole rounds
-    on 256x160 tiles and the remaining 11264 rows as a second launch with a row offset (GemmP::m_off).  Bit-identical to a single launch
-    (knob 1024), and spot-checked against torch."""
+    on 256x160 tiles and the remaining 11264 rows as a second launch with a row offset (GemmP::m_off) - since round 4 only under knob 32768,
+    the default being one launch of the halo kernel.  All three forms bit-identical (knob 1024 = im2col in a single launch), spot-checked against torch."""
     rng = np.random.default_rng(320 + C1)
     T, H, W, C0, O = 25, 48, 64, 320, 320
     x = rnd(rng, T, H, W, C0)
@@ -524,12 +524,15 @@ def test_conv_row_split_bitwise_full_size(engine, C1):
     w = rnd(rng, O, C0 + C1, 1, 3, 3, scale=(9 * (C0 + C1)) ** -0.5)
     b = rnd(rng, O)
     try:
-        got = engine.op_conv(x, w, b, x1=x1)
-        engine.tune_force(-100 - 1024, 0)
-        one = engine.op_conv(x, w, b, x1=x1)
+        halo = engine.op_conv(x, w, b, x1=x1)                     # round 4 default: ONE launch of the halo kernel on 256 x 128 tiles
+        engine.tune_force(-100 - 32768, 0)
+        got = engine.op_conv(x, w, b, x1=x1)                      # knob 32768: the row-split im2col pair (the default until round 3)
+        engine.tune_force(-100 - 32768 - 1024, 0)
+        one = engine.op_conv(x, w, b, x1=x1)                      # + knob 1024: im2col in a single launch
     finally:
         engine.tune_force(-100, 0)
     assert np.array_equal(got, one), f"row split changes the result: max diff {np.abs(got - one).max()}"
+    assert np.array_equal(halo, one), f"halo kernel vs im2col: max diff {np.abs(halo - one).max()}"
     xin = x if x1 is None else np.concatenate([x, x1], -1)
     for t_ in (0, 21, 24):        # frame 21 straddles the split row (65536 = 21 frames + 1024 rows)
         ref = conv_ref(xin[t_:t_ + 1], w.reshape(O, C0 + C1, 3, 3), b)

@@ -19,7 +19,7 @@ setter = {"conv_split": lambda on: eng.tune_force(-100 - (0 if on else 1024), 0)
           "flash": lambda on: eng.tune_flash(7 if on else 3), "flashlazy": lambda on: eng.tune_flash(23 if on else 7), "flashpp": lambda on: eng.tune_flash(87 if on else 23),
           "snsmall": lambda on: eng.tune_force(-100 - (0 if on else 8192), 0), "insitu": lambda on: eng.tune_force(-100 - (0 if on else 4096), 0),
           "lvl3": lambda on: eng.tune_force(-100 - (0 if on else 2048), 0), "ffxt": lambda on: eng.tune_ff(0 if on else 1),
-          "halo": lambda on: eng.tune_force(-100 - (0 if on else 16384), 0), "halo_l0": lambda on: eng.tune_force(-100 - (32768 if on else 0), 0),
+          "halo": lambda on: eng.tune_force(-100 - (0 if on else 16384), 0), "halo_l0": lambda on: eng.tune_force(-100 - (0 if on else 32768), 0),
           "ff_fused": lambda on: eng.set_ff_fused(on, prenorm=on), "ff_ln": lambda on: eng.set_ff_fused(True, prenorm=on), "fp8": eng.set_fp8_linears, "vae32": eng.set_vae_encode_fp32,
           "lanes": lambda on: eng.set_concurrency(3 if on else 1), "lanes2": lambda on: eng.set_concurrency(2 if on else 1), "lanes4": lambda on: eng.set_concurrency(4 if on else 1)}[what]
 eng.run(25, 8)

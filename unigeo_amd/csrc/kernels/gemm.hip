@@ -1336,12 +1336,14 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
   // them (tools: 76800 rows, 320 -> 320 channels: 127 + 37 us against 185 - 190 us for any single tiling).  Knob 1024 = off.
   bool planned = p0.cfg_p1 == 0;          // the caller took the planner's choice (run_gemm passes it back explicitly) - not a tuning override
   if (!planned && (p.tune_cfg_p1 - 1) < 0) { int c2, s2; gemm_plan(p0, batch, &c2, &s2); planned = (c2 == cfg && s2 == split); }
-  if (planned && p.conv && p.kt == 1 && p.ky == 3 && p.kx == 3 && p.N % 160 == 0 && p.N <= 320 && split == 1 && batch == 1 && !p.up_phase && !(p.flags & (UG_F_OUT_F32 | UG_F_GEGLU)) &&
+  const bool halo_on = planned && !(p.tune_knobs & 16384) && split == 1 && (p.tune_cfg_p1 - 1) < 0 && !(p.flags & UG_F_GEGLU);
+  const bool halo_l0 = halo_on && p.N % 160 == 0 && p.N <= 320 && !(p.tune_knobs & 32768) && conv_halo_supported(p, batch, 256, 128);
+  if (!halo_l0 && planned && p.conv && p.kt == 1 && p.ky == 3 && p.kx == 3 && p.N % 160 == 0 && p.N <= 320 && split == 1 && batch == 1 && !p.up_phase && !(p.flags & (UG_F_OUT_F32 | UG_F_GEGLU)) &&
       (p.tune_cfg_p1 - 1) < 0 && !(p.tune_knobs & 1024) && gemm_can_bufa(p, 64, true)) {
     const long ntn = p.N / 160, tiles = (long)cdiv(p.M, 256) * ntn, whole = tiles / 256 * 256, rem = tiles - whole;
     if (whole > 0 && rem > 0 && rem * 2 <= 256) {
       const int M1 = (int)(whole / ntn) * 256;
-      const bool halo = (p.tune_knobs & 32768) != 0;             // A/B: halo-staged form of both launches (measured slower on the 256 x 160 tile)
+      const bool halo = false;                                    // (the halo kernel takes these convolutions as ONE launch on 256 x 128 tiles instead - below; knob 32768 = this row split, A/B)
       GemmP a = p; a.M = M1; a.cfg_p1 = 61;                     // config 60 (+ 1)
       GemmP b = p0; b.M = p.M - M1; b.m_off = M1; b.Out = (void*)((f16*)p.Out + (long)M1 * p.ldo);
       if (p.flags & UG_F_NOXCD) b.flags |= UG_F_NOXCD;
@@ -1360,11 +1362,13 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
       return;
     }
   }
-  if (planned && !(p.tune_knobs & 16384) && split == 1 && (p.tune_cfg_p1 - 1) < 0 && !(p.flags & UG_F_GEGLU)) {
+  if (halo_on) {
     // Round 4: every halo-stageable 3x3 convolution goes to the halo kernel (kernels/conv_halo.hip) - of its tiles the one whose tile count fills
     // the 256 CUs best.  tools/ab_halo.py, profiles/r04_conv_halo.txt: 0.81 - 0.92 x the im2col time on levels 1 / 2 of the UNet, 0.72 - 0.95 x on the
-    // VAE decoder; the 256 x 160 tile (level 0: 320 columns) measures 1.02 - 1.08 x and stays on the row-split im2col path above unless knob 32768
-    // forces it.  Bit-identical outputs (same products, same K order).  Knob 16384 = off (A/B).
+    // VAE decoder.  Level 0 (320 columns; tools/ab_halo_l0.py): ONE launch on 256 x 128 tiles - three column tiles, a sixth of the third wasted -
+    // runs the 320 -> 320 convolution in 145 us against 177 for the row-split im2col pair, 153 for 256 x 160 halo tiles in one launch and 183
+    // for the row split on halo tiles (the thin second launch is what costs).  Bit-identical outputs.  Knob 16384 = halo off, 32768 = level 0 stays
+    // on the row-split im2col path (A/B).
     int best = -1; double bfill = 0.0;
     for (int c = 70; c <= 73; ++c) {
       const int bm = c <= 71 ? 256 : 192, bn = (c == 70 || c == 73) ? 160 : 128;
@@ -1374,7 +1378,9 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
       const double fill = (double)tiles / (cdiv(tiles, 256) * 256.0) * useful * (bm == 256 ? 1.0 : 0.97);
       if (fill > bfill) { bfill = fill; best = c; }
     }
-    if (best >= 0 && (best != 70 || (p.tune_knobs & 32768))) cfg = best;
+    if (halo_l0) best = 71;
+    else if (p.N % 160 == 0 && p.N <= 320) best = -1;             // knob 32768: the row split above took it, or it is not stageable
+    if (best >= 0) cfg = best;
   }
   if (split > 1) UG_REQUIRE(p.partial != nullptr, "split-K needs a partial buffer");
   p.group_m = pick_group_m(p, cfg, batch, split);
