@@ -15,6 +15,8 @@ clip = synthetic_clip(T, H, W)
 frames = DepthCrafter.prepare_input(None, clip)
 nl, na = make_noise(T, H, W, 0)
 eng.set_inputs(frames, nl, na, np.stack(clip["intrinsics"], 0))
+if os.environ.get("UG_TUNE_KNOBS"):     # GEMM knob mask for this run (kernels/gemm.hip), e.g. 16384 = halo conv off
+    eng.tune_force(-100 - int(os.environ["UG_TUNE_KNOBS"]), -1)
 if os.environ.get("UG_FP8"):
     eng.set_fp8_linears(True)           # BASELINE configs[4] option: MX-fp8 linear layers
 if os.environ.get("UG_NO_FF_FUSED"):

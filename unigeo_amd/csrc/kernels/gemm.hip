@@ -1337,7 +1337,8 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
   bool planned = p0.cfg_p1 == 0;          // the caller took the planner's choice (run_gemm passes it back explicitly) - not a tuning override
   if (!planned && (p.tune_cfg_p1 - 1) < 0) { int c2, s2; gemm_plan(p0, batch, &c2, &s2); planned = (c2 == cfg && s2 == split); }
   const bool halo_on = planned && !(p.tune_knobs & 16384) && split == 1 && (p.tune_cfg_p1 - 1) < 0 && !(p.flags & UG_F_GEGLU);
-  const bool halo_l0 = halo_on && p.N % 160 == 0 && p.N <= 320 && !(p.tune_knobs & 32768) && conv_halo_supported(p, batch, 256, 128);
+  // (level 0, in situ - tools/profile_shapes.py: 320 -> 320 171 vs 189 us; the two-source convolutions of the up path 299 vs 297 and 432 vs 412: they keep the row split)
+  const bool halo_l0 = halo_on && p.N % 160 == 0 && p.N <= 320 && p.C1 == 0 && !(p.tune_knobs & 32768) && conv_halo_supported(p, batch, 256, 128);
   if (!halo_l0 && planned && p.conv && p.kt == 1 && p.ky == 3 && p.kx == 3 && p.N % 160 == 0 && p.N <= 320 && split == 1 && batch == 1 && !p.up_phase && !(p.flags & (UG_F_OUT_F32 | UG_F_GEGLU)) &&
       (p.tune_cfg_p1 - 1) < 0 && !(p.tune_knobs & 1024) && gemm_can_bufa(p, 64, true)) {
     const long ntn = p.N / 160, tiles = (long)cdiv(p.M, 256) * ntn, whole = tiles / 256 * 256, rem = tiles - whole;
