@@ -477,6 +477,36 @@ def test_ff_fused_with_in_kernel_layernorm(engine, M, C, rpv):
     assert_close(got, two, 1.5e-3, f"in-kernel LayerNorm vs three launches {M}x{C}")
 
 
+@pytest.mark.parametrize("M,N,bias,res,c0,c1", [
+    (76800, 320, True, True, 1.0, 1.0),      # level-0 attention output / proj_out (+ residual)
+    (76800, 960, False, False, 1.0, 1.0),    # level-0 fused Q | K | V projection: three column groups
+    (19200, 320, True, True, 0.7, 0.3),      # scaled residual blend
+    (16420, 640, True, False, 1.0, 1.0),     # ragged last tile (16420 = 513 x 32 + 4), two column groups
+    (16384, 320, False, True, 1.0, 1.0),     # the smallest M the planner sends here
+])
+def test_stream_gemm_bitwise_and_reference(engine, M, N, bias, res, c0, c1):
+    """Weight-stationary streaming GEMM of the short-K (K = 320) projections (kernels/gemm_stream.hip: W resident in registers, activation rows
+    through a 4-slot LDS ring) against the tiled kernels it replaces (knob 65536 = off): same MFMA chain, same K order -> bit-identical;
+    the tiled result against fp32 torch on sampled rows."""
+    rng = np.random.default_rng(M + N)
+    K = 320
+    A, W = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5)
+    b = rnd(rng, N) if bias else None
+    R = rnd(rng, M, N) if res else None
+    try:
+        engine.tune_force(-100 - 65536, -1)
+        ref = engine.op_linear(A, W, b, R1=R, c0=c0, c1=c1)
+        engine.tune_force(-100 - 0, -1)
+        got = [engine.op_linear(A, W, b, R1=R, c0=c0, c1=c1) for _ in range(2)]
+    finally:
+        engine.tune_force(-100 - 0, -1)
+    assert np.array_equal(got[0], got[1])
+    assert np.array_equal(got[0], ref), f"streaming vs tiled GEMM: max diff {np.abs(got[0] - ref).max()}"
+    rows = _rows(rng, M, 64)
+    y = c0 * (t(A[rows]) @ t(W).T + (t(b) if bias else 0.0)) + (c1 * t(R[rows]) if res else 0.0)
+    assert_close(ref[rows], y.numpy(), TOL, f"tiled reference itself {M}x{N}x{K}")
+
+
 @pytest.mark.parametrize("T,H,W,C0,C1,O", [
     (1, 16, 16, 64, 0, 128),        # one 16 x 16 tile
     (2, 48, 64, 128, 0, 320),       # 320 columns: level-0 geometry (three 128-column tiles, the third half empty)

@@ -91,6 +91,9 @@ void launch_gemm_mx8(const GemmP& p, hipStream_t s);   // dense only; C0 = lda a
 // fp16 [M, K] (row stride ldx) -> e4m3 bytes [M, K] + e8m0 scales (layout above, ld_s >= round_up(M, 256)); K % 128 == 0
 void launch_quant_mx8(const f16* x, long ldx, long M, int K, unsigned char* q, unsigned* scales, long ld_s, hipStream_t s);
 void launch_gemm(const GemmP& p, int batch, hipStream_t s);
+// weight-stationary streaming GEMM for K = 320, N in {320, 640, 960} (kernels/gemm_stream.hip; tile config 80): dense, fp16 out, bias + one residual
+bool gemm_stream_supported(const GemmP& p, int batch);
+void launch_gemm_stream(const GemmP& p, hipStream_t s);
 // halo-staged 3x3 convolution (kernels/conv_halo.hip; tile configs 70 / 71 = 256 x 160 / 256 x 128, 72 / 73 = 192 x 128 / 192 x 160 output pixels x columns): stride 1, pad 1, chunk-major weights, whole 256-pixel tiles
 bool conv_halo_supported(const GemmP& p, int batch, int bm, int bn);
 void launch_conv_halo(const GemmP& p, int bm, int bn, hipStream_t s);

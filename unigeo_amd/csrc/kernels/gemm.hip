@@ -1083,6 +1083,7 @@ static void launch_cfg(int cfg, const GemmP& p, int batch, hipStream_t s) {
     case 71: UG_REQUIRE(conv_halo_supported(p, batch, 256, 128), "config 71: not a halo-stageable convolution"); launch_conv_halo(p, 256, 128, s); break;
     case 72: UG_REQUIRE(conv_halo_supported(p, batch, 192, 128), "config 72: not a halo-stageable convolution"); launch_conv_halo(p, 192, 128, s); break;
     case 73: UG_REQUIRE(conv_halo_supported(p, batch, 192, 160), "config 73: not a halo-stageable convolution"); launch_conv_halo(p, 192, 160, s); break;
+    case 80: launch_gemm_stream(p, s); break;   // weight-stationary streaming GEMM (kernels/gemm_stream.hip)
     default: UG_REQUIRE(false, "unknown / pruned GEMM tile config");
   }
 }
@@ -1382,6 +1383,11 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
     if (halo_l0) best = 71;
     else if (p.N % 160 == 0 && p.N <= 320) best = -1;             // knob 32768: the row split above took it, or it is not stageable
     if (best >= 0) cfg = best;
+  }
+  if (planned && !(p.tune_knobs & 65536) && (p.tune_cfg_p1 - 1) < 0 && split == 1 && gemm_stream_supported(p, batch)) {
+    // Round 4: the short-K projections of the narrow level (K = 320 onto 320 / 960 columns) on the weight-stationary streaming kernel
+    // (kernels/gemm_stream.hip); bit-identical.  Knob 65536 = off (A/B).
+    cfg = 80;
   }
   if (split > 1) UG_REQUIRE(p.partial != nullptr, "split-K needs a partial buffer");
   p.group_m = pick_group_m(p, cfg, batch, split);
