@@ -158,9 +158,7 @@ struct Ctx {
   // link rate instead of the runtime's chunked staging of a pageable hipMemcpy (slot 0: inputs, 1: outputs); grown on demand
   void* pin[2] = {nullptr, nullptr}; size_t pin_sz[2] = {0, 0};
   int ff_fused = 3;          // bit 0: fused GEGLU feed-forward kernel for the narrow (C <= 320) transformer blocks (0 = two GEMM launches);
-                             // bit 1: its LayerNorm (+ broadcast row added to the residual stream) applied inside that kernel (A/B runs);
-                             // bit 2: LayerNorm -> Q|K|V projection as one kernel on the same blocks (ln_linear_kernel, round 3) - OFF by default:
-                             // measured slower than the LayerNorm launch + GEMM it replaces (137 vs 113 us at 76800 x 960 x 320)
+                             // bit 1: its LayerNorm (+ broadcast row added to the residual stream) applied inside that kernel (A/B runs)
   int fp8_linears = 0;       // 1 = run the UNet's eligible linear layers on MX-fp8 MFMAs (BASELINE configs[4]; reduced precision, off by default)
   int vae_encode_fp32 = 1;   // 1 = reference behaviour (float32-grade encoder), 0 = fp16 storage like the decoder
   // lanes (run_lanes): streams are created on first use; lane_need remembers the arena bytes a task kind needed when it first ran serially

@@ -948,7 +948,8 @@ static void ff_pair(Ctx& c, const f16* a, long M, const Lin& f1, const Lin& f2, 
 }
 
 // out[M, l.out] = LayerNorm(x) . W^T (+ bias): the LayerNorm launch (writing t1) followed by the GEMM.  (Round 3 also had ONE kernel with the
-// activation tile resident in LDS for the narrow level; 130 - 137 us against 113 - 117 for the pair at 76800 x 960 x 320 - removed in round 4.)
+// activation tile resident in LDS for the narrow level; 130 - 137 us against 113 - 117 for the pair at 76800 x 960 x 320 - removed in round 4.  Round 4
+// tried it again inside the streaming GEMM (kernels/gemm_stream.hip): correct, +2.5 ms per clip - removed as well.)
 static void ln_linear(Ctx& c, const f16* x, long M, const Norm& ln, f16* t1, const Lin& l, f16* out, const QAct* q) {
   layernorm(c, x, M, ln, t1, nullptr, 1, nullptr, q);
   Epi e;

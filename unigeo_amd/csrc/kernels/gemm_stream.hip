@@ -18,9 +18,15 @@
 #include "gemm_common.h"
 #include <algorithm>
 
-template <int dummy>
-__global__ __launch_bounds__(384, 2) void gemm_stream320_kernel(const GemmP p, int ngroups, int wg_per_group) {
-  constexpr int BM = 32, KT = 5, NSLOT = 4, NCW = 5;
+// Measured and removed (round 4): (i) deeper rings - 5 ... 8 slots, one or two fetch waves - run the same or 2 - 5 % slower than 4 slots: the loop is
+// not short of bytes in flight; (ii) the LayerNorm in front of the Q | K | V projection done INSIDE this kernel (two more waves normalising tile
+// i + 1 in LDS while tile i is multiplied; op-level tests green): clip 975.3 / 974.4 ms against 972.3 / 971.8 for LayerNorm launch + this kernel.
+template <int NSLOT, int NF>   // ring slots, fetch waves (each loads 20 / NF KiB of a tile: vmcnt counts <= 63 loads)
+__global__ __launch_bounds__((5 + NF) * 64, 2) void gemm_stream320_kernel(const GemmP p, int ngroups, int wg_per_group) {
+  constexpr int BM = 32, KT = 5, NCW = 5;
+  constexpr int LEAD = 0;                            // tile i + LEAD has landed at the barrier that starts iteration i
+  constexpr int LPT = 20 / NF;                       // loads per fetch wave per tile
+  static_assert((NSLOT - 2) * LPT <= 63 && NSLOT * 20 <= 160 && NSLOT >= 3 + LEAD, "vmcnt range / LDS");
   constexpr int TILE = KT * BM * 64;                 // halves per activation tile: [KT][32 rows][64]
   constexpr unsigned SENT = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) f16 ring[];   // [NSLOT][TILE] = 80 KiB
@@ -31,15 +37,17 @@ __global__ __launch_bounds__(384, 2) void gemm_stream320_kernel(const GemmP p, i
   const int ntiles = (p.M + BM - 1) / BM;
   const int my_tiles = wslot < ntiles ? (ntiles - wslot + wg_per_group - 1) / wg_per_group : 0;
 
-  if (wave == NCW) {
-    // ================================= fetch wave =================================
+  if (wave >= NCW) {
+    // ================================= fetch waves =================================
+    const int fw = wave - NCW;                       // fetch wave fw loads row groups j = fw * (4 / NF) .. of every K tile
     const int pc = lane & 7, lrow = lane >> 3;
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A0, 0, (int)SENT, 0x00020000);
-    unsigned roff[4];                                // byte offset of (row j*8 + lrow, swizzled chunk) inside a tile's K tile 0
+    constexpr int JPW = 4 / NF;
+    unsigned roff[JPW];                              // byte offset of (row j*8 + lrow, swizzled chunk) inside a tile's K tile 0
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = j * 8 + lrow;
-      roff[j] = (unsigned)r * (unsigned)(p.C0 * 2) + (unsigned)((pc ^ swz<64>(r)) * 16);
+    for (int jj = 0; jj < JPW; ++jj) {
+      const int r = (fw * JPW + jj) * 8 + lrow;
+      roff[jj] = (unsigned)r * (unsigned)(p.C0 * 2) + (unsigned)((pc ^ swz<64>(r)) * 16);
     }
     auto issue = [&](int ti) {                       // tile index of this workgroup
       const int m0 = (wslot + ti * wg_per_group) * BM;
@@ -47,41 +55,50 @@ __global__ __launch_bounds__(384, 2) void gemm_stream320_kernel(const GemmP p, i
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int jj = 0; jj < JPW; ++jj) {
+          const int j = fw * JPW + jj;
           const bool ok = m0 + j * 8 + lrow < p.M;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(dst + (kt * BM + j * 8) * 64), 16, ok ? (int)roff[j] : (int)SENT, (m0 * p.C0 + kt * 64) * 2, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(dst + (kt * BM + j * 8) * 64), 16, ok ? (int)roff[jj] : (int)SENT, (m0 * p.C0 + kt * 64) * 2, 0, 0);
         }
     };
-    // NSLOT - 1 tiles in flight; tile i must have landed before the barrier that starts iteration i
+    // NSLOT - 1 tiles issued ahead; tile it + LEAD must have landed before the barrier that starts iteration it (it = -LEAD: the LayerNorm waves'
+    // first tile)
     for (int t = 0; t < NSLOT - 1 && t < my_tiles; ++t) issue(t);
-    for (int i = 0; i < my_tiles; ++i) {
-      // landed: tile i; younger tiles that may still be in flight: min(NSLOT - 2, my_tiles - 1 - i) of 20 loads each
-      const int younger = min(NSLOT - 2, my_tiles - 1 - i);
-      if (younger >= 2) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-      else if (younger == 1) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                  // publishes tile i; everybody has left the slot of tile i - 1
-      if (i + NSLOT - 1 < my_tiles) issue(i + NSLOT - 1);   // into the slot of tile i - 1
+    for (int it = -LEAD; it < my_tiles; ++it) {
+      // younger tiles that may still be in flight behind tile it + LEAD: issued so far = up to it + NSLOT - 2
+      const int younger = max(0, min(it + NSLOT - 2, my_tiles - 1) - (it + LEAD));
+      switch (younger) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT <= 63 ? 3 * LPT : 63) : "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPT <= 63 ? 4 * LPT : 63) : "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * LPT <= 63 ? 5 * LPT : 63) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * LPT <= 63 ? 6 * LPT : 63) : "memory"); break;
+      }
+      __builtin_amdgcn_s_barrier();                  // publishes tile it + LEAD; everybody has left the slot of tile it - 1
+      if (it >= 0 && it + NSLOT - 1 < my_tiles) issue(it + NSLOT - 1);   // into the slot of tile it - 1
     }
     return;
   }
-
   // ================================= compute waves =================================
   const int l15 = lane & 15, g = lane >> 4;
   const int nbase = grp * 320 + wave * 64;           // this wave's 64 output columns
   // W fragments, resident: MFMA "A" operand of n-tile j, K step s = W row nbase + perm(j, l15), K [s*32 + g*8, +8);
-  // perm: row i of n-tile j <-> column (i >> 2) * 16 + j * 4 + (i & 3), so that lane group g ends up with columns g*16 + [0, 16)
+  // perm: row i of n-tile j <-> column (j >> 1) * 32 + (i >> 2) * 8 + (j & 1) * 4 + (i & 3): lane group g ends up with the two 8-column runs
+  // [g*8, +8) and [32 + g*8, +8) of the wave's 64 columns, so that the four lanes of a row write 64 contiguous bytes per store instruction
+  // (16 contiguous columns per lane, as in the tiled kernels' epilogue, make every store instruction write 16-byte pieces 32 bytes apart)
   f16x8 wf[4][10];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int n = nbase + (l15 >> 2) * 16 + j * 4 + (l15 & 3);
+    const int n = nbase + (j >> 1) * 32 + (l15 >> 2) * 8 + (j & 1) * 4 + (l15 & 3);
     const f16* wr = p.W + (long)n * p.ldw + g * 8;
 #pragma unroll
     for (int s = 0; s < 10; ++s) wf[j][s] = n < p.N ? *(const f16x8*)(wr + s * 32) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
   }
-  const int nc = nbase + g * 16;                     // first of this lane's 16 output columns
+  const int nc = nbase + g * 8;                      // this lane's columns: nc + [0, 8) and nc + 32 + [0, 8)
   f16x8 bb[2] = {(f16x8){0, 0, 0, 0, 0, 0, 0, 0}, (f16x8){0, 0, 0, 0, 0, 0, 0, 0}};
-  if (p.bias) { bb[0] = *(const f16x8*)(p.bias + nc); bb[1] = *(const f16x8*)(p.bias + nc + 8); }
+  if (p.bias) { bb[0] = *(const f16x8*)(p.bias + nc); bb[1] = *(const f16x8*)(p.bias + nc + 32); }
   // fragment read offsets (halves) inside a tile: row block b, K step s -> (kt = s >> 1, kk = s & 1)
   int aoff[2][2];
 #pragma unroll
@@ -89,15 +106,21 @@ __global__ __launch_bounds__(384, 2) void gemm_stream320_kernel(const GemmP p, i
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) { const int r = b * 16 + l15; aoff[b][kk] = r * 64 + (((kk * 4 + g) ^ swz<64>(r)) * 8); }
 
-  for (int i = 0; i < my_tiles; ++i) {
-    const int m0 = (wslot + i * wg_per_group) * BM;
-    // residual rows of this tile: issued before the barrier, consumed after the MFMAs
-    f16x8 r1[2][2];
+  // residual rows: the loads of tile i + 1 are issued at the END of iteration i (into the registers the epilogue has just consumed), so they have
+  // the barrier wait and the MFMAs of the next iteration to land
+  f16x8 r1[2][2];
+  auto load_r1 = [&](int ti) {
+    const int m0 = (wslot + ti * wg_per_group) * BM;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const long m = m0 + b * 16 + l15;
-      if (p.R1) { const f16* rp = p.R1 + (m < p.M ? m : 0) * p.ldr1 + nc; r1[b][0] = *(const f16x8*)rp; r1[b][1] = *(const f16x8*)(rp + 8); }
+      const f16* rp = p.R1 + (m < p.M ? m : 0) * p.ldr1 + nc;
+      r1[b][0] = *(const f16x8*)rp; r1[b][1] = *(const f16x8*)(rp + 32);
     }
+  };
+  if (p.R1 && my_tiles > 0) load_r1(0);
+  for (int i = 0; i < my_tiles; ++i) {
+    const int m0 = (wslot + i * wg_per_group) * BM;
     __builtin_amdgcn_s_barrier();                    // tile i is in its slot
     asm volatile("" ::: "memory");
     const f16* T = ring + (i % NSLOT) * TILE;
@@ -120,7 +143,6 @@ __global__ __launch_bounds__(384, 2) void gemm_stream320_kernel(const GemmP p, i
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const long m = m0 + b * 16 + l15;
-      if (m >= p.M) continue;
       float o[16];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -133,9 +155,12 @@ __global__ __launch_bounds__(384, 2) void gemm_stream320_kernel(const GemmP p, i
       f16x8 h0, h1;
 #pragma unroll
       for (int e = 0; e < 8; ++e) { h0[e] = (f16)o[e]; h1[e] = (f16)o[8 + e]; }
-      f16* op = (f16*)p.Out + m * p.ldo + nc;
-      *(f16x8*)op = h0; *(f16x8*)(op + 8) = h1;
+      if (m < p.M) {
+        f16* op = (f16*)p.Out + m * p.ldo + nc;
+        *(f16x8*)op = h0; *(f16x8*)(op + 32) = h1;
+      }
     }
+    if (p.R1 && i + 1 < my_tiles) load_r1(i + 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 }
@@ -152,9 +177,10 @@ void launch_gemm_stream(const GemmP& p, hipStream_t s) {
   const int ngroups = p.N / 320;
   const int ntiles = cdiv(p.M, 32);
   const int wpg = std::max(1, std::min(256 / ngroups, ntiles));
-  const size_t lds = 4 * 5 * 32 * 64 * sizeof(f16);
-  static bool attr[32] = {};
-  bool& at = attr[ug_dev_slot()];
-  if (!at) { UG_CHECK(hipFuncSetAttribute((const void*)gemm_stream320_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); at = true; }
-  hipLaunchKernelGGL(gemm_stream320_kernel<0>, dim3(ngroups * wpg), dim3(384), lds, s, p, ngroups, wpg);
+  auto go = [&](auto kern, int nslot, int nwave) {
+    const size_t lds = (size_t)nslot * 5 * 32 * 64 * sizeof(f16);
+    UG_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(ngroups * wpg), dim3(nwave * 64), lds, s, p, ngroups, wpg);
+  };
+  go(gemm_stream320_kernel<4, 1>, 4, 6);
 }
