@@ -7,7 +7,7 @@
 // 4.3 - 5.  Here the WEIGHTS never move: a workgroup owns a 320-column group of W for its whole life, held in registers as MFMA fragments
 // (5 compute waves x 64 columns x 320 K = 160 VGPRs per lane), and the activation rows stream through a 4-slot LDS ring of 32-row tiles
 // (20 KiB each, direct-to-LDS loads by a sixth wave, two to three tiles = 40 - 60 KB in flight per CU at all times).  Per 32-row tile a
-// compute wave issues 20 fragment reads and 80 MFMAs (1280 cycles) against ~6000 cycles of HBM time for the tile's 60 KB: the loop is
+// compute wave issues 20 fragment reads and 80 MFMAs (1280 cycles; one 16-row block after the other) against ~6000 cycles of HBM time for the tile's 60 KB: the loop is
 // paced by memory, as it should be.  One s_barrier per tile; the epilogue (bias, residuals, 32-byte stores per lane) is the compute waves' own
 // plain loads / stores - only the fetch wave has direct-to-LDS loads in flight, so its counted vmcnt never sees them.  One residual (R1), one bias.
 //
@@ -97,8 +97,9 @@ __global__ __launch_bounds__((5 + NF) * 64, 2) void gemm_stream320_kernel(const 
     for (int s = 0; s < 10; ++s) wf[j][s] = n < p.N ? *(const f16x8*)(wr + s * 32) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
   }
   const int nc = nbase + g * 8;                      // this lane's columns: nc + [0, 8) and nc + 32 + [0, 8)
+  constexpr int NC2 = 32;                            // distance of the lane's second 8-column run
   f16x8 bb[2] = {(f16x8){0, 0, 0, 0, 0, 0, 0, 0}, (f16x8){0, 0, 0, 0, 0, 0, 0, 0}};
-  if (p.bias) { bb[0] = *(const f16x8*)(p.bias + nc); bb[1] = *(const f16x8*)(p.bias + nc + 32); }
+  if (p.bias) { bb[0] = *(const f16x8*)(p.bias + nc); bb[1] = *(const f16x8*)(p.bias + nc + NC2); }
   // fragment read offsets (halves) inside a tile: row block b, K step s -> (kt = s >> 1, kk = s & 1)
   int aoff[2][2];
 #pragma unroll
@@ -118,36 +119,35 @@ __global__ __launch_bounds__((5 + NF) * 64, 2) void gemm_stream320_kernel(const 
       r1[b][0] = *(const f16x8*)rp; r1[b][1] = *(const f16x8*)(rp + 32);
     }
   };
+  // The resident W fragments / bias must be complete HERE: otherwise the compiler's wait for them sits at the first MFMA of the loop body, as a
+  // vmcnt(0) that every iteration executes - and that also waits for the previous tile's stores to be acknowledged (~2 us per tile: the loop ran at
+  // 3.3 us per tile whatever the bytes; seen in the ISA).  The builtin form is the one the wait-count pass takes into account.
+  __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
   if (p.R1 && my_tiles > 0) load_r1(0);
   for (int i = 0; i < my_tiles; ++i) {
     const int m0 = (wslot + i * wg_per_group) * BM;
     __builtin_amdgcn_s_barrier();                    // tile i is in its slot
     asm volatile("" ::: "memory");
     const f16* T = ring + (i % NSLOT) * TILE;
-    f32x4 acc[2][4];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[b][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < 10; ++s) {
-      f16x8 af[2];
-#pragma unroll
-      for (int b = 0; b < 2; ++b) af[b] = *(const f16x8*)(T + (s >> 1) * BM * 64 + aoff[b][s & 1]);
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][s], af[b], acc[b][j], 0, 0, 0);
-    }
-    // (the slot is handed back by the NEXT barrier: all fragment reads above are complete when their MFMAs have issued)
+    // one 16-row block at a time: 16 accumulator registers live instead of 32 (with both blocks live the kernel spilled a W fragment, and the
+    // reload's vmcnt(0) inside the loop made every tile wait for the previous tile's stores to be acknowledged)
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 10; ++s) {
+        const f16x8 af = *(const f16x8*)(T + (s >> 1) * BM * 64 + aoff[b][s & 1]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][s], af, acc[j], 0, 0, 0);
+      }
       const long m = m0 + b * 16 + l15;
       float o[16];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[j * 4 + r] = p.c0 * (acc[b][j][r] + (float)bb[(j * 4 + r) >> 3][(j * 4 + r) & 7]);
+        for (int r = 0; r < 4; ++r) o[j * 4 + r] = p.c0 * (acc[j][r] + (float)bb[(j * 4 + r) >> 3][(j * 4 + r) & 7]);
       if (p.R1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { o[e] += p.c1 * (float)r1[b][0][e]; o[8 + e] += p.c1 * (float)r1[b][1][e]; }
@@ -166,7 +166,9 @@ __global__ __launch_bounds__((5 + NF) * 64, 2) void gemm_stream320_kernel(const 
 }
 
 bool gemm_stream_supported(const GemmP& p, int batch) {
-  if (p.conv || batch != 1 || p.K != 320 || p.N % 320 || p.N > 960 || p.M < 16384) return false;   // (tools/ab_stream.py: 0.64 - 0.73 x the tiled time at M = 76800, 0.88 at 19200, 1.2 - 1.3 x at 5184)
+  // tools/ab_stream.py: 0.63 - 0.72 x the tiled time at M = 76800, 0.9 at 19200, 1.2 - 1.3 x at 5184.  (A GEGLU form for the feed-forward tail rows,
+  // 11264 x 2560 x 320, measured 40.3 against 41.4 us in the clip and was removed.)
+  if (p.conv || batch != 1 || p.K != 320 || p.N % 320 || p.N > 960 || p.M < 16384) return false;
   if (p.act != UG_ACT_NONE || (p.flags & (UG_F_GEGLU | UG_F_OUT_F32 | UG_F_R1_F32)) || p.splitk > 1 || p.up_phase || p.R2 || p.bias2) return false;
   if ((p.C0 & 7) || (p.ldw & 7) || (p.ldo & 7) || (p.R1 && (p.ldr1 & 7))) return false;
   return (long)p.M * p.C0 * 2 < (1L << 31) - 64;
