@@ -1,0 +1,7 @@
+python -m pytest tests/test_ops_gpu.py -x -q -k "ff_fused" 2>&1 | tail -3
+python tools/bench_ff.py 2>&1 | tail -12
+for i in 1 2; do
+python tools/time_clip.py 3 2>&1 | tail -1
+UG_TUNE_KNOBS=131072 python tools/time_clip.py 3 2>&1 | tail -1
+done
+python -m pytest tests/test_fullsize_golden_gpu.py tests/test_trajectory_gpu.py -x -q 2>&1 | tail -3
