@@ -425,7 +425,7 @@ def main():
             ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
             res["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_TFLOPS_F16, 4), "traffic": None,
-                               "kernel": "gemm_kernel<...> + gemm_ws_kernel<...> + gemm_ldr_kernel<...> + conv_halo_kernel<...> (all linear / 3x3 / 1x1 / temporal-conv / attention GEMM launches)",
+                               "kernel": "gemm_kernel<...> + gemm_ws_kernel<...> + gemm_ldr_kernel<...> + conv_halo_kernel<...> + gemm_stream320_kernel<...> (all linear / 3x3 / 1x1 / temporal-conv / attention GEMM launches)",
                                "launches": g_calls, "avg_launch_us": round(g_ms * 1000.0 / max(g_calls, 1), 2),
                                "algorithmic_tflop": round(g_fl / 1e12, 2),
                                "note": "algorithmic FLOPs (SURVEY 8d): a nearest-2x upsample + 3x3 conv is credited its 9-tap FLOPs although the "

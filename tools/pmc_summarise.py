@@ -10,7 +10,7 @@ for d in sys.argv[1:]:
         h.update(open(f, "rb").read())
         for row in csv.DictReader(open(f)):
             kn = row.get("Kernel_Name", "")
-            if "gemm_kernel" in kn or "gemm_ldr_kernel" in kn or "gemm_ws_kernel" in kn or "ff_fused_kernel" in kn or "conv_halo_kernel" in kn:
+            if "gemm_kernel" in kn or "gemm_ldr_kernel" in kn or "gemm_ws_kernel" in kn or "gemm_stream320_kernel" in kn or "ff_fused_kernel" in kn or "conv_halo_kernel" in kn:
                 tot += float(row["Counter_Value"]); n += 1; name = row["Counter_Name"]
     out[name or os.path.basename(d)] = {"sum": tot, "dispatch_rows": n, "csv_sha256": h.hexdigest()}
 print(json.dumps(out))

@@ -12,7 +12,7 @@ if [ "$STEPS" = "sn" ]; then WL="tools/one_image_sn.py"; ARG=""; else WL="tools/
 python $WL $ARG --events gpurun_out/pmc_events.json > gpurun_out/pmc_events.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$C
-  timeout 1500 rocprofv3 --pmc $C --kernel-include-regex "gemm_(kernel|ldr_kernel|ws_kernel)|ff_fused_kernel|conv_halo_kernel" --output-format csv -d gpurun_out/pmc_$C -o pmc -- python $WL $ARG > gpurun_out/pmc_$C.log 2>&1 || true
+  timeout 1500 rocprofv3 --pmc $C --kernel-include-regex "gemm_(kernel|ldr_kernel|ws_kernel|stream320_kernel)|ff_fused_kernel|conv_halo_kernel" --output-format csv -d gpurun_out/pmc_$C -o pmc -- python $WL $ARG > gpurun_out/pmc_$C.log 2>&1 || true
 done
 python tools/pmc_summarise.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
 if [ "$STEPS" = "sn" ]; then mv gpurun_out/pmc_traffic_gemm.json gpurun_out/pmc_traffic_gemm_sn.json; fi
