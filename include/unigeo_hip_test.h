@@ -52,6 +52,10 @@ int ug_op_linear_mx8(ug_ctx* ctx, const float* A, int M, int K, const float* W, 
 int ug_op_conv(ug_ctx* ctx, const float* x0_thwc, int C0, const float* x1_thwc, int C1, int T, int H, int W,
                const float* weight /*[O][I][kt][ky][kx]*/, const float* bias, int O, int kt, int k, int stride,
                int pad_t, int pad_l, int ups, float* out_thwc);
+/* convolution (k x k pad k/2, or (kt,1,1)) + residual, then GroupNorm + SiLU of its output with the statistics (a) from a pass over the stored tensor,
+ * (b) from the convolution's epilogue (GemmP::stat_part); *rb_out = rows per statistics block (0: the planner's kernel has no statistics epilogue) */
+int ug_op_conv_gn(ug_ctx* ctx, const float* x_thwc, int C0, int T, int H, int W, const float* weight, const float* bias, const float* res, int O, int kt, int k,
+                  int G, float eps, int temporal, const float* gamma, const float* beta, float* conv_out, float* y_pass, float* y_epi, int* rb_out);
 int ug_op_groupnorm(ug_ctx* ctx, const float* x0, int C0, const float* x1, int C1, int T, int HW, int G, float eps,
                     int temporal, int silu, const float* gamma, const float* beta, float* out);
 int ug_op_layernorm(ug_ctx* ctx, const float* x, int M, int C, float eps, const float* gamma, const float* beta,

@@ -542,6 +542,45 @@ def test_conv_halo_bitwise_and_reference(engine, T, H, W, C0, C1, O):
         assert_close(ref, conv_ref(xx, w, b), TOL, "im2col reference itself")
 
 
+@pytest.mark.parametrize("T,H,W,C,O,kt,k,temporal,res,want_rb", [
+    (25, 24, 32, 640, 640, 1, 3, False, False, 48),    # UNet level 1, halo kernel on 192 x 128 tiles: blocks of 48 rows
+    (25, 24, 32, 640, 640, 1, 3, True, True, 48),      # ... + residual, statistics pooled over the frames (the temporal block's first GroupNorm)
+    (25, 48, 64, 320, 320, 1, 3, False, False, 64),    # level 0, halo kernel on 256 x 128 tiles (three column tiles, the third half empty)
+    (25, 24, 32, 640, 640, 3, 1, True, True, -1),      # temporal convolution on the producer / consumer kernel (48- or 96-row blocks by wave layout)
+    (25, 12, 16, 1280, 1280, 1, 3, False, True, 48),   # level 2: statistics written, GroupNorm keeps its one-launch slab form there
+    (2, 96, 128, 128, 128, 1, 3, False, False, 48),    # VAE decoder geometry
+    (3, 20, 24, 64, 64, 1, 3, False, False, 0),        # ragged tiles: the planner's kernel declines, GroupNorm runs its statistics pass
+])
+def test_groupnorm_statistics_from_conv_epilogue(engine, T, H, W, C, O, kt, k, temporal, res, want_rb):
+    """GroupNorm statistics from the producing convolution's epilogue (GemmP::stat_part, tile_epilogue_stats -> gn_finalize_cols) against the
+    statistics pass over the stored tensor: the convolution's output is bit-identical (checked inside ug_op_conv_gn), the two GroupNorm outputs
+    agree to fp32-summation-order effects on (mean, rstd) - a few fp16 ulps on isolated elements - and both match fp32 torch on the stored tensor."""
+    rng = np.random.default_rng(T * H * W + C + kt)
+    x = rnd(rng, T, H, W, C)
+    w = rnd(rng, O, C, kt, k, k, scale=(kt * k * k * C) ** -0.5)
+    b = rnd(rng, O)
+    r = rnd(rng, T, H, W, O) if res else None
+    gamma, beta = h16(1.0 + 0.2 * rng.standard_normal(O)), h16(0.1 * rng.standard_normal(O))
+    co, y_pass, y_epi, rb = engine.op_conv_gn(x, w, b, 32, 1e-5, gamma, beta, res=r, kt=kt, k=k, temporal=temporal)
+    if want_rb >= 0:
+        assert rb == want_rb, f"rows per statistics block {rb}, expected {want_rb}"
+    else:
+        assert rb in (48, 96), rb
+    xt = torch.from_numpy(co.reshape(T, H * W, O)).float()
+    G, cpg = 32, O // 32
+    xg = xt.reshape(T, H * W, G, cpg)
+    dims = (0, 1, 3) if temporal else (1, 3)
+    mean = xg.mean(dim=dims, keepdim=True)
+    var = xg.var(dim=dims, keepdim=True, unbiased=False)
+    yn = ((xg - mean) / torch.sqrt(var + 1e-5)).reshape(T, H * W, O) * t(gamma) + t(beta)
+    ref = torch.nn.functional.silu(yn).numpy().reshape(T, H, W, O)
+    assert_close(y_pass, ref, 2e-3, "GroupNorm with a statistics pass")
+    assert_close(y_epi, ref, 2e-3, "GroupNorm with the statistics from the convolution's epilogue")
+    d = np.abs(y_epi - y_pass)
+    assert d.max() <= 4e-3 * max(1.0, float(np.abs(ref).max())), f"epilogue vs pass statistics: max diff {d.max()}"
+    assert (d > 0).mean() < 0.02, f"epilogue vs pass statistics: {(d > 0).mean():.3%} of the elements differ"
+
+
 @pytest.mark.parametrize("C1", [0, 320])
 def test_conv_row_split_bitwise_full_size(engine, C1):
     """3x3 convolution onto 320 channels at the clip's level-0 size (25 x 48 x 64 = 76800 rows): launch_gemm runs the rows of the whole rounds

@@ -20,7 +20,7 @@ EXPORTS = [
     "ug_load_tensor", "ug_bind_unet", "ug_bind_vae", "ug_bind_clip",
     "ug_dc_set_inputs", "ug_dc_run", "ug_dc_run_windows", "ug_dc_get_outputs", "ug_dc_device_ptrs", "ug_dc_set_trace", "ug_set_vae_encode_fp32", "ug_set_concurrency", "ug_set_fp8_linears", "ug_op_linear_mx8", "ug_set_ff_fused", "ug_op_ff", "ug_op_ln_ff", "ug_bench_ff", "ug_bench_flash", "ug_tune_flash", "ug_tune_ff",
     "ug_eval_depth", "ug_eval_normal", "ug_clip_embed", "ug_vae_encode", "ug_vae_decode", "ug_unet_forward", "ug_normals_from_depth",
-    "ug_op_linear", "ug_op_conv", "ug_op_groupnorm", "ug_op_layernorm", "ug_op_flash_attn",
+    "ug_op_linear", "ug_op_conv", "ug_op_conv_gn", "ug_op_groupnorm", "ug_op_layernorm", "ug_op_flash_attn",
     "ug_op_temporal_attn", "ug_op_attention_generic", "ug_op_flash_attn_dh", "ug_op_euler_step",
     "ug_bind_stablenormal", "ug_sn_run", "ug_sn_unet_forward", "ug_sn_dino", "ug_sn_vae_decode", "ug_sn_vae_encode", "ug_resize_bilinear",
     "ug_profile_begin", "ug_profile_begin_shapes", "ug_profile_end", "ug_bench_gemm", "ug_bench_groupnorm", "ug_bench_mfma_peak", "ug_tune_force",
@@ -106,6 +106,7 @@ def load_library():
     lib.ug_op_linear.argtypes = [vp, vp, ip, ip, vp, ip, vp, vp, C.c_float, C.c_float, ip, ip, vp]
     lib.ug_op_conv.argtypes = [vp, vp, ip, vp, ip, ip, ip, ip, vp, vp, ip, ip, ip, ip, ip, ip, ip, vp]
     lib.ug_op_groupnorm.argtypes = [vp, vp, ip, vp, ip, ip, ip, ip, C.c_float, ip, ip, vp, vp, vp]
+    lib.ug_op_conv_gn.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, vp, ip, ip, ip, ip, C.c_float, ip, vp, vp, vp, vp, vp, vp]
     lib.ug_op_layernorm.argtypes = [vp, vp, ip, ip, C.c_float, vp, vp, vp, ip, vp, vp]
     lib.ug_op_flash_attn.argtypes = [vp, vp, ip, ip, ip, vp]
     lib.ug_op_temporal_attn.argtypes = [vp, vp, ip, ip, ip, vp]
@@ -459,6 +460,17 @@ class Engine:
         self._ck(self.lib.ug_op_groupnorm(self.ctx, _ptr(x0), C0, _ptr(x1a), C1, T, HW, G, eps, int(temporal), int(silu),
                                           _ptr(_f32(gamma)), _ptr(_f32(beta)), _ptr(out)))
         return out
+
+    def op_conv_gn(self, x, w, b, G, eps, gamma, beta, res=None, kt=1, k=3, temporal=False):
+        """conv (+ residual) -> GroupNorm + SiLU with the statistics from a pass over the tensor / from the convolution's epilogue:
+        (conv_out, y_pass, y_epi, rows_per_statistics_block)."""
+        x = _f32(x); T, H, W, C0 = x.shape; w = _f32(w); O = w.shape[0]
+        r = None if res is None else _f32(res)
+        co = np.empty((T, H, W, O), np.float32); y1 = np.empty_like(co); y2 = np.empty_like(co)
+        rb = C.c_int(0)
+        self._ck(self.lib.ug_op_conv_gn(self.ctx, _ptr(x), C0, T, H, W, _ptr(w), _ptr(None if b is None else _f32(b)), _ptr(r), O, kt, k, G, eps, int(temporal),
+                                        _ptr(_f32(gamma)), _ptr(_f32(beta)), _ptr(co), _ptr(y1), _ptr(y2), C.byref(rb)))
+        return co, y1, y2, rb.value
 
     def op_layernorm(self, x, eps, gamma, beta, addvec=None, rows_per_vec=1):
         x = _f32(x); M, Cc = x.shape

@@ -693,6 +693,52 @@ int ug_op_conv(ug_ctx* x, const float* x0, int C0, const float* x1, int C1, int 
   });
 }
 
+// conv (3x3 pad 1, or (kt,1,1) temporal) + optional residual, then GroupNorm (+SiLU) of its output two ways: statistics pass over the stored tensor
+// (y_pass) and statistics from the convolution's epilogue (GemmP::stat_part -> GroupNormP::part; y_epi).  rb_out: rows per statistics block the
+// launch reported (0: the planner's kernel cannot, y_epi then equals y_pass by construction).  conv_out: the convolution's output (both runs: must be bit-identical).
+int ug_op_conv_gn(ug_ctx* x, const float* x0, int C0, int T, int H, int W, const float* weight, const float* bias, const float* res, int O, int kt, int k,
+                  int G, float eps, int temporal, const float* gamma, const float* beta, float* conv_out, float* y_pass, float* y_epi, int* rb_out) {
+  UG_TRY(x, {
+    Ctx& c = x->c; Scope sc(c);
+    const int I = C0, taps = kt * k * k;
+    UG_REQUIRE(I % 64 == 0, "ug_op_conv_gn: channels must be a multiple of 64");
+    std::vector<float> wp((size_t)O * taps * I);
+    for (int o = 0; o < O; ++o) for (int i = 0; i < I; ++i) for (int tp = 0; tp < taps; ++tp)
+      wp[(((size_t)o * (I / 64) + i / 64) * taps + tp) * 64 + i % 64] = weight[((size_t)o * I + i) * taps + tp];
+    const long M = (long)T * H * W;
+    f16* d0 = up16(c, x0, M * C0); f16* dW = up16(c, wp.data(), (long)wp.size()); f16* db = up16_opt(c, bias, O);
+    f16* dR = up16_opt(c, res, M * O);
+    f16* dg = up16(c, gamma, O); f16* dbt = up16(c, beta, O);
+    f16* o1 = c.ws.get<f16>(M * O); f16* o2 = c.ws.get<f16>(M * O); f16* y1 = c.ws.get<f16>(M * O); f16* y2 = c.ws.get<f16>(M * O);
+    float2* part = (float2*)c.ws.get<float>(((M + 47) / 48) * (long)O * 2);
+    int rb = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      GemmP p; memset(&p, 0, sizeof(p));
+      p.conv = 1; p.A0 = d0; p.C0 = C0; p.T = T; p.Hi = H; p.Wi = W; p.Ho = H; p.Wo = W;
+      p.ups = 1; p.stride = 1; p.pad_t = k / 2; p.pad_l = k / 2; p.kt = kt; p.ky = k; p.kx = k;
+      p.M = (int)M; p.N = O; p.K = I * taps; p.W = dW; p.ldw = p.K; p.bias = db; p.c0 = 1.f; p.R1 = dR; p.ldr1 = O; p.c1 = 1.f;
+      p.Out = pass ? o2 : o1; p.ldo = O; p.zero = c.zero; p.nb_inner = 1; p.kchunk = taps > 1;
+      gemm_apply_tune(p, c.tune);
+      const size_t mk = c.ws.mark();
+      { int cf, sp; gemm_plan(p, 1, &cf, &sp); p.cfg_p1 = cf + 1; p.splitk = sp; if (sp > 1) p.partial = c.ws.get<float>((long)sp * p.M * p.N); }
+      if (pass) { p.stat_part = part; p.stat_hw = H * W; launch_gemm(p, 1, c.stream, &rb); } else launch_gemm(p, 1, c.stream);
+      c.ws.release(mk);
+      GroupNormP g; memset(&g, 0, sizeof(g));
+      g.X0 = pass ? o2 : o1; g.C0 = O; g.T = T; g.HW = H * W; g.G = G; g.eps = eps; g.temporal = temporal; g.silu = 1; g.gamma = dg; g.beta = dbt;
+      g.Y = pass ? y2 : y1; g.ws = c.ws.get<float>((long)groupnorm_ws_floats(T, H * W, O, G));
+      if (pass && rb > 0) { g.part = part; g.part_rb = rb; }
+      launch_groupnorm(g, c.stream);
+      c.ws.release(mk);
+    }
+    *rb_out = rb;
+    down16(c, o1, conv_out, M * O);
+    std::vector<float> tmp((size_t)M * O);
+    down16(c, o2, tmp.data(), M * O);
+    UG_REQUIRE(memcmp(tmp.data(), conv_out, tmp.size() * 4) == 0, "ug_op_conv_gn: the statistics epilogue changed the convolution's output");
+    down16(c, y1, y_pass, M * O); down16(c, y2, y_epi, M * O);
+  });
+}
+
 int ug_op_groupnorm(ug_ctx* x, const float* x0, int C0, const float* x1, int C1, int T, int HW, int G, float eps,
                     int temporal, int silu, const float* gamma, const float* beta, float* out) {
   UG_TRY(x, {

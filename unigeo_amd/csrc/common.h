@@ -82,6 +82,10 @@ struct GemmP {
   int halo_tw, halo_lg;  // set by launch_conv_halo only (kernels/conv_halo.hip): the tile is (256 / halo_tw) x halo_tw output pixels of one frame, halo_tw = 1 << halo_lg;
                          // the epilogue maps tile row r to launch row m0 + (r >> halo_lg) * Wo + (r & (halo_tw - 1))
   int tune_cfg_p1, tune_split_p1, tune_knobs;   // GemmTune of the launching context, + 1 so that a zeroed GemmP means "no override"
+  // GroupNorm statistics of the OUTPUT from the epilogue (round 4): per block of `rb` consecutive output rows (rb = the wave tile's rows, reported by
+  // launch_gemm) and per column the sum / sum of squares of the fp16 values stored, stat_part[blk * N + n]; stat_hw = output rows per frame (blocks
+  // must not straddle frames).  launch_gemm declines (reports rb = 0, writes nothing) when the chosen kernel cannot: split-K, ragged tiles, ...
+  float2* stat_part; int stat_hw;
 };
 // tuning overrides (A/B tools and the tile-config tests; ug_tune_force sets them on ONE context, the engine copies them into every GemmP):
 // cfg / split -1 = planner's choice; knobs = bit mask documented in kernels/gemm.hip
@@ -90,7 +94,7 @@ static inline void gemm_apply_tune(GemmP& p, const GemmTune& t) { p.tune_cfg_p1 
 void launch_gemm_mx8(const GemmP& p, hipStream_t s);   // dense only; C0 = lda and ldw in BYTES (= elements)
 // fp16 [M, K] (row stride ldx) -> e4m3 bytes [M, K] + e8m0 scales (layout above, ld_s >= round_up(M, 256)); K % 128 == 0
 void launch_quant_mx8(const f16* x, long ldx, long M, int K, unsigned char* q, unsigned* scales, long ld_s, hipStream_t s);
-void launch_gemm(const GemmP& p, int batch, hipStream_t s);
+void launch_gemm(const GemmP& p, int batch, hipStream_t s, int* stat_rb = nullptr);   // stat_rb: rows per statistics block written (0 = none), see GemmP::stat_part
 // weight-stationary streaming GEMM for K = 320, N in {320, 640, 960} (kernels/gemm_stream.hip; tile config 80): dense, fp16 out, bias + one residual
 bool gemm_stream_supported(const GemmP& p, int batch);
 void launch_gemm_stream(const GemmP& p, hipStream_t s);
@@ -126,6 +130,9 @@ struct GroupNormP {
   f16* Y;                 // [T*HW, C0+C1]
   float* ws;              // >= T * G * 2 * nchunk floats (+ T*G*2 for mean/rstd)
   int mode;               // 0 = automatic; 1 / 2 / 4 / 6 force a launch scheme (launch_groupnorm)
+  // statistics already reduced per block of part_rb rows and per channel by the producing GEMM's epilogue (GemmP::stat_part; single source, HW % part_rb == 0):
+  // gn_finalize_cols + gn_apply, no pass over X for the statistics
+  const float2* part; int part_rb;
 };
 void launch_groupnorm(const GroupNormP& p, hipStream_t s);
 size_t groupnorm_ws_floats(int T, int HW, int C, int G);

@@ -199,9 +199,18 @@ struct Epi {
   const f16* R2 = nullptr; long ldr2 = 0; float c2 = 1.f; float c0 = 1.f; int act = 0; int flags = 0;
   const unsigned char* a8 = nullptr; const unsigned* sa8 = nullptr; long ld_sa8 = 0;   // A already in MX-fp8 (written by the producing LayerNorm)
   float alg = 1.f;   // algorithmic / executed FLOPs of this launch (0.5 for the K-doubled hi/lo-pair GEMMs of the float32-grade encoder)
+  struct StatPart* so = nullptr; int stat_hw = 0;   // GroupNorm statistics of the output from the epilogue (stat_hw: rows per frame of a dense output)
 };
+// GroupNorm statistics handed from the producing GEMM's epilogue to the GroupNorm that follows (GemmP::stat_part): allocated by the caller next to the
+// tensor, filled by conv() / linear() when the chosen kernel can (rb = rows per block, 0 = not written: groupnorm() then runs its statistics pass)
+struct StatPart { float2* part = nullptr; int rb = 0; };
+static StatPart stat_alloc(Ctx& c, long M, int N) {
+  StatPart s;
+  if (!(c.tune.knobs & 131072) && M >= 8192) s.part = (float2*)c.ws.get<float>(((M + 47) / 48) * (long)N * 2);   // 48 = the smallest wave tile; M >= 8192: below that GroupNorm keeps its one- / two-launch slab forms (4096 measured: +2 ms per clip)
+  return s;
+}
 
-static void run_gemm(Ctx& c, GemmP p, int batch, const char* tag, float alg = 1.f) {
+static void run_gemm(Ctx& c, GemmP p, int batch, const char* tag, float alg = 1.f, StatPart* so = nullptr, int stat_hw = 0) {
   p.zero = c.zero;
   gemm_apply_tune(p, c.tune);
   if (p.nb_inner < 1) p.nb_inner = 1;
@@ -221,7 +230,8 @@ static void run_gemm(Ctx& c, GemmP p, int batch, const char* tag, float alg = 1.
     const double bytes = 2.0 * batch * (a_el + (double)p.N * p.K + (double)p.M * nout * ((p.flags & UG_F_OUT_F32) ? 2 : 1) +
                                         (p.R1 ? (double)p.M * nout : 0.0) + (p.R2 ? (double)p.M * nout : 0.0));
     ProfScope ps(c, nm, 2.0 * p.M * p.N * (double)p.K * batch * (p.up_phase ? 2.25 : 1.0) * alg, bytes);
-    launch_gemm(p, batch, c.stream);
+    if (so && so->part) { p.stat_part = so->part; p.stat_hw = p.conv ? p.Ho * p.Wo : stat_hw; }
+    launch_gemm(p, batch, c.stream, so && so->part ? &so->rb : nullptr);
   }
   c.ws.release(mk);
 }
@@ -285,7 +295,7 @@ static void linear(Ctx& c, const f16* A, long M, const Lin& l, f16* out, const E
   p.Out = out; p.ldo = ldo ? ldo : nout;
   if (p.R1 && !p.ldr1) p.ldr1 = nout;
   if (p.R2 && !p.ldr2) p.ldr2 = nout;
-  run_gemm(c, p, 1, "gemm_linear", e.alg);
+  run_gemm(c, p, 1, "gemm_linear", e.alg, e.so, e.stat_hw);
 }
 
 // implicit-GEMM convolution over channels-last sources
@@ -317,13 +327,14 @@ static void conv(Ctx& c, const f16* x0, int C0, const f16* x1, int C1, int T, in
   p.R1 = e.R1; p.ldr1 = e.ldr1 ? e.ldr1 : cv.cout; p.c1 = e.c1;
   p.R2 = e.R2; p.ldr2 = e.ldr2 ? e.ldr2 : cv.cout; p.c2 = e.c2; p.c0 = e.c0; p.act = e.act; p.flags = e.flags;
   p.Out = out; p.ldo = ldo ? ldo : cv.cout; p.kchunk = cv.kchunk;
-  run_gemm(c, p, 1, cv.kt > 1 ? "gemm_tconv" : (cv.ky > 1 ? "gemm_conv3x3" : "gemm_conv1x1"), e.alg);
+  run_gemm(c, p, 1, cv.kt > 1 ? "gemm_tconv" : (cv.ky > 1 ? "gemm_conv3x3" : "gemm_conv1x1"), e.alg, e.so);
 }
 
 static void groupnorm(Ctx& c, const f16* x0, int C0, const f16* x1, int C1, int T, int HW, int G, const Norm& n,
-                      int temporal, int silu, f16* y) {
+                      int temporal, int silu, f16* y, const StatPart* sp = nullptr) {
   UG_REQUIRE(C0 + C1 == n.c, "groupnorm channel mismatch");
   GroupNormP p; memset(&p, 0, sizeof(p));
+  if (sp && sp->part && sp->rb > 0 && C1 == 0 && HW % sp->rb == 0) { p.part = sp->part; p.part_rb = sp->rb; }
   p.X0 = x0; p.X1 = x1; p.C0 = C0; p.C1 = C1; p.T = T; p.HW = HW; p.G = G; p.eps = n.eps;
   p.temporal = temporal; p.silu = silu; p.gamma = n.g; p.beta = n.b; p.Y = y;
   const size_t mk = c.ws.mark();
@@ -855,16 +866,17 @@ void test_unfused_attention(Ctx& c, const f16* qkv, long ld, int B, int S, int H
 
 // ResnetBlock2D over a (virtual concat) input; out [M, cout] must be pre-allocated
 static void res2d_forward(Ctx& c, const Res2D& r, const f16* x0, int C0, const f16* x1, int C1, int T, int h, int w,
-                          int G, const f16* tproj, f16* out) {
+                          int G, const f16* tproj, f16* out, StatPart* out_stats = nullptr, const StatPart* in_stats = nullptr) {
   const long M = (long)T * h * w;
   const int cin = C0 + C1, cout = r.c1.cout;
   const size_t mk = c.ws.mark();
   f16* a = c.ws.get<f16>(M * cin);
-  groupnorm(c, x0, C0, x1, C1, T, h * w, G, r.n1, 0, 1, a);
+  groupnorm(c, x0, C0, x1, C1, T, h * w, G, r.n1, 0, 1, a, C1 == 0 ? in_stats : nullptr);
   f16* hb = c.ws.get<f16>(M * cout);
-  { Epi e; e.bias2 = tproj; conv(c, a, cin, nullptr, 0, T, h, w, r.c1, 1, 1, 1, 1, hb, e); }
+  StatPart sh = stat_alloc(c, M, cout);      // the statistics of the second GroupNorm come out of the first convolution's epilogue
+  { Epi e; e.bias2 = tproj; e.so = &sh; conv(c, a, cin, nullptr, 0, T, h, w, r.c1, 1, 1, 1, 1, hb, e); }
   f16* b = c.ws.get<f16>(M * cout);
-  groupnorm(c, hb, cout, nullptr, 0, T, h * w, G, r.n2, 0, 1, b);
+  groupnorm(c, hb, cout, nullptr, 0, T, h * w, G, r.n2, 0, 1, b, &sh);
   const f16* res = x0;
   if (r.has_sc) {
     f16* scb = hb;   // hb is dead after the second GroupNorm
@@ -873,25 +885,29 @@ static void res2d_forward(Ctx& c, const Res2D& r, const f16* x0, int C0, const f
   } else {
     UG_REQUIRE(C1 == 0, "identity shortcut needs a single source");
   }
-  { Epi e; e.R1 = res; e.ldr1 = cout; conv(c, b, cout, nullptr, 0, T, h, w, r.c2, 1, 1, 1, 1, out, e); }
+  { Epi e; e.R1 = res; e.ldr1 = cout; e.so = out_stats; conv(c, b, cout, nullptr, 0, T, h, w, r.c2, 1, 1, 1, 1, out, e); }
   c.ws.release(mk);
 }
 
+// in_stats: epilogue statistics of x0 (single source) from whatever produced it; out_stats: filled with those of the block's output (the caller hands
+// them to the next block's / the transformer's first GroupNorm) - allocated next to `out`, same lifetime
 static f16* stres_forward(Ctx& c, const STRes& rb, const f16* x0, int C0, const f16* x1, int C1, int T, int h, int w,
-                          int G, const f16* tproj_s, const f16* tproj_t) {
+                          int G, const f16* tproj_s, const f16* tproj_t, StatPart* out_stats = nullptr, const StatPart* in_stats = nullptr) {
   const long M = (long)T * h * w;
   const int cout = rb.cout;
   f16* out = c.ws.get<f16>(M * cout);
+  if (out_stats) *out_stats = stat_alloc(c, M, cout);
   const size_t mk = c.ws.mark();
   f16* xs = c.ws.get<f16>(M * cout);
-  res2d_forward(c, rb.s, x0, C0, x1, C1, T, h, w, G, tproj_s, xs);
+  StatPart sx = stat_alloc(c, M, cout), sh = stat_alloc(c, M, cout);
+  res2d_forward(c, rb.s, x0, C0, x1, C1, T, h, w, G, tproj_s, xs, &sx, in_stats);
   f16* a = c.ws.get<f16>(M * cout);
-  groupnorm(c, xs, cout, nullptr, 0, T, h * w, G, rb.t.n1, 1, 1, a);
+  groupnorm(c, xs, cout, nullptr, 0, T, h * w, G, rb.t.n1, 1, 1, a, &sx);
   f16* hb = c.ws.get<f16>(M * cout);
-  { Epi e; e.bias2 = tproj_t; conv(c, a, cout, nullptr, 0, T, h, w, rb.t.c1, 1, 0, 0, 1, hb, e); }
-  groupnorm(c, hb, cout, nullptr, 0, T, h * w, G, rb.t.n2, 1, 1, a);
+  { Epi e; e.bias2 = tproj_t; e.so = &sh; conv(c, a, cout, nullptr, 0, T, h, w, rb.t.c1, 1, 0, 0, 1, hb, e); }
+  groupnorm(c, hb, cout, nullptr, 0, T, h * w, G, rb.t.n2, 1, 1, a, &sh);
   // blend: alpha*xs + (1-alpha)*(xs + conv) = xs + (1-alpha)*conv
-  { Epi e; e.c0 = 1.f - rb.alpha; e.R1 = xs; e.ldr1 = cout; e.c1 = 1.f; conv(c, a, cout, nullptr, 0, T, h, w, rb.t.c2, 1, 0, 0, 1, out, e); }
+  { Epi e; e.c0 = 1.f - rb.alpha; e.R1 = xs; e.ldr1 = cout; e.c1 = 1.f; e.so = out_stats; conv(c, a, cout, nullptr, 0, T, h, w, rb.t.c2, 1, 0, 0, 1, out, e); }
   c.ws.release(mk);
   return out;
 }
@@ -991,13 +1007,13 @@ static void ln_ff(Ctx& c, const f16* x, long M, const Norm& ln, const f16* addve
   ff_pair(c, t1, M, f1, f2, mid, out, e2, q);
 }
 
-static f16* transformer_forward(Ctx& c, const Transformer& tr, const f16* x, int T, int h, int w, int G) {
+static f16* transformer_forward(Ctx& c, const Transformer& tr, const f16* x, int T, int h, int w, int G, const StatPart* in_stats = nullptr) {
   const int C = tr.C, HW = h * w;
   const long M = (long)T * HW;
   f16* out = c.ws.get<f16>(M * C);
   const size_t mk = c.ws.mark();
   f16* t1 = c.ws.get<f16>(M * C);
-  groupnorm(c, x, C, nullptr, 0, T, HW, G, tr.gn, 0, 0, t1);
+  groupnorm(c, x, C, nullptr, 0, T, HW, G, tr.gn, 0, 0, t1, in_stats);
   f16* h0 = c.ws.get<f16>(M * C);
   linear(c, t1, M, tr.proj_in, h0);
   // fp8 linear path: the LayerNorms feeding a linear layer write MX-fp8 directly (no fp16 copy, no separate quantiser pass)
@@ -1136,33 +1152,37 @@ f16* unet_forward(Ctx& c, const f16* x, int T, int h, int w, int step) {
   int ch = cfg.boc[0], ch_h = h, ch_w = w;
   f16* cur = c.ws.get<f16>((long)T * h * w * ch);
   conv(c, x, cfg.in_ch, nullptr, 0, T, h, w, u.conv_in, 1, 1, 1, 1, cur);
+  StatPart cs;      // epilogue statistics of `cur` (valid while its producer was a convolution that could write them)
   skips.push_back({cur, ch});
   for (int i = 0; i < n; ++i) {
     for (int j = 0; j < cfg.layers; ++j) {
       const STRes& r = u.down[i].res[j];
-      cur = stres_forward(c, r, cur, ch, nullptr, 0, T, ch_h, ch_w, G, tp_s(r), tp_t(r));
-      ch = r.cout;
-      if (cfg.has_attn[i]) cur = transformer_forward(c, u.down[i].attn[j], cur, T, ch_h, ch_w, G);
+      StatPart so;
+      cur = stres_forward(c, r, cur, ch, nullptr, 0, T, ch_h, ch_w, G, tp_s(r), tp_t(r), &so, cs.part ? &cs : nullptr);
+      ch = r.cout; cs = so;
+      if (cfg.has_attn[i]) { cur = transformer_forward(c, u.down[i].attn[j], cur, T, ch_h, ch_w, G, &cs); cs = StatPart(); }
       skips.push_back({cur, ch});
     }
     if (u.down[i].has_down) {
       f16* d = c.ws.get<f16>((long)T * (ch_h / 2) * (ch_w / 2) * ch);
       conv(c, cur, ch, nullptr, 0, T, ch_h, ch_w, u.down[i].down, 2, 1, 1, 1, d);
-      ch_h /= 2; ch_w /= 2; cur = d;
+      ch_h /= 2; ch_w /= 2; cur = d; cs = StatPart();
       skips.push_back({cur, ch});
     }
   }
-  cur = stres_forward(c, u.mid0, cur, ch, nullptr, 0, T, ch_h, ch_w, G, tp_s(u.mid0), tp_t(u.mid0));
-  cur = transformer_forward(c, u.mid_attn, cur, T, ch_h, ch_w, G);
+  { StatPart so;
+    cur = stres_forward(c, u.mid0, cur, ch, nullptr, 0, T, ch_h, ch_w, G, tp_s(u.mid0), tp_t(u.mid0), &so, cs.part ? &cs : nullptr);
+    cur = transformer_forward(c, u.mid_attn, cur, T, ch_h, ch_w, G, &so); }
   cur = stres_forward(c, u.mid1, cur, ch, nullptr, 0, T, ch_h, ch_w, G, tp_s(u.mid1), tp_t(u.mid1));
   for (int i = 0; i < n; ++i) {
     const int lev = n - 1 - i;
     for (size_t j = 0; j < u.up[i].res.size(); ++j) {
       const STRes& r = u.up[i].res[j];
       const Skip sk = skips.back(); skips.pop_back();
-      cur = stres_forward(c, r, cur, ch, sk.p, sk.C, T, ch_h, ch_w, G, tp_s(r), tp_t(r));
+      StatPart so;
+      cur = stres_forward(c, r, cur, ch, sk.p, sk.C, T, ch_h, ch_w, G, tp_s(r), tp_t(r), &so);
       ch = r.cout;
-      if (cfg.has_attn[lev]) cur = transformer_forward(c, u.up[i].attn[j], cur, T, ch_h, ch_w, G);
+      if (cfg.has_attn[lev]) cur = transformer_forward(c, u.up[i].attn[j], cur, T, ch_h, ch_w, G, &so);
     }
     if (u.up[i].has_up) {
       f16* d = c.ws.get<f16>((long)T * (ch_h * 2) * (ch_w * 2) * ch);
@@ -1369,24 +1389,28 @@ void vae_decode(Ctx& c, const f16* z, int T, int h, int w, float* frames_out) {
   f16* cur = c.ws.get<f16>(M0 * ch);
   conv(c, z8, 8, nullptr, 0, T, h, w, v.d_in, 1, 1, 1, 1, cur);
   cur = stres_forward(c, v.dmid[0], cur, ch, nullptr, 0, T, ch_h, ch_w, G, nullptr, nullptr);
+  StatPart cs;      // epilogue statistics of `cur` (res-block -> res-block chains: the next block's first GroupNorm needs no statistics pass)
   for (size_t j = 1; j < v.dmid.size(); ++j) {
     if (j == 1) cur = vattn_forward(c, v.dattn, cur, T, ch_h * ch_w, G);
-    cur = stres_forward(c, v.dmid[j], cur, ch, nullptr, 0, T, ch_h, ch_w, G, nullptr, nullptr);
+    StatPart so;
+    cur = stres_forward(c, v.dmid[j], cur, ch, nullptr, 0, T, ch_h, ch_w, G, nullptr, nullptr, &so, cs.part ? &cs : nullptr);
+    cs = so;
   }
   for (int i = 0; i < n; ++i) {
     for (auto& r : v.dup[i].res) {
-      cur = stres_forward(c, r, cur, ch, nullptr, 0, T, ch_h, ch_w, G, nullptr, nullptr);
-      ch = r.cout;
+      StatPart so;
+      cur = stres_forward(c, r, cur, ch, nullptr, 0, T, ch_h, ch_w, G, nullptr, nullptr, &so, cs.part ? &cs : nullptr);
+      ch = r.cout; cs = so;
     }
     if (v.dup[i].has_up) {
       f16* d = c.ws.get<f16>((long)T * (ch_h * 2) * (ch_w * 2) * ch);
       conv(c, cur, ch, nullptr, 0, T, ch_h, ch_w, v.dup[i].up, 1, 1, 1, 2, d);
-      ch_h *= 2; ch_w *= 2; cur = d;
+      ch_h *= 2; ch_w *= 2; cur = d; cs = StatPart();
     }
   }
   const long M = (long)T * ch_h * ch_w;
   f16* a = c.ws.get<f16>(M * ch);
-  groupnorm(c, cur, ch, nullptr, 0, T, ch_h * ch_w, G, v.d_norm, 0, 1, a);
+  groupnorm(c, cur, ch, nullptr, 0, T, ch_h * ch_w, G, v.d_norm, 0, 1, a, cs.part ? &cs : nullptr);
   f16* rgb = c.ws.get<f16>(M * 8);
   conv(c, a, ch, nullptr, 0, T, ch_h, ch_w, v.d_out, 1, 1, 1, 1, rgb, Epi(), 8);
   {

@@ -25,7 +25,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-template <int BM, int BN, int LG>
+template <int BM, int BN, int LG, bool ST = false>   // ST: GroupNorm statistics of the output from the epilogue (GemmP::stat_part)
 __global__ __launch_bounds__(12 * 64, 3) void conv_halo_kernel(const GemmP p) {
   constexpr int BK = 64, NCW = 8, WMW = 4, WNW = 2;
   constexpr unsigned SENT = 0x80000000u;
@@ -247,7 +247,8 @@ __global__ __launch_bounds__(12 * 64, 3) void conv_halo_kernel(const GemmP p) {
     if (tap == 8 && last_chunk) {
       int t, y0, x0, n0; tile_origin(wslot + ti * nwg, t, y0, x0, n0);
       const int m0 = (t * p.Ho + y0) * p.Wo + x0 - p.m_off;
-      tile_epilogue<MT, NT, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, 0);
+      if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, (t * tpf + (y0 / TH) * txn + (x0 >> LG)) * (BM / WTM) + wm);
+      else tile_epilogue<MT, NT, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, 0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all fragment reads of this slot / this halo are done before they are handed back
     __builtin_amdgcn_s_barrier();
@@ -290,14 +291,14 @@ bool conv_halo_supported(const GemmP& p, int batch, int bm, int bn) {
   return halo_pick_lg(p, bm, bn) >= 0;
 }
 
-template <int BM, int BN, int LG>
+template <int BM, int BN, int LG, bool ST = false>
 static void launch_halo_t(const GemmP& p, hipStream_t s) {
   constexpr int TW = 1 << LG, TH = BM >> LG, PITCH = (TW + 2 + 7) & ~7, NG = (TH + 2) * (PITCH / 8);
   const size_t lds = 2 * (size_t)NG * 1024 + 3 * (size_t)BN * 128;
   static bool attr[32] = {};
   bool& at = attr[ug_dev_slot()];
   if (!at) {
-    UG_CHECK(hipFuncSetAttribute((const void*)conv_halo_kernel<BM, BN, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UG_CHECK(hipFuncSetAttribute((const void*)conv_halo_kernel<BM, BN, LG, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     at = true;
   }
   const int ntiles = (p.M / BM) * cdiv(p.N, BN);
@@ -305,12 +306,18 @@ static void launch_halo_t(const GemmP& p, hipStream_t s) {
   static const bool dbg = getenv("UG_HALO_DEBUG") != nullptr;
   if (dbg) fprintf(stderr, "[halo] %dx%d M %d (m_off %d) N %d C %d+%d  %dx%d  tile %dx%d pitch %d  lds %zu  grid %d\n", BM, BN, p.M, p.m_off, p.N, p.C0, p.C1, p.Ho, p.Wo, TH, TW, PITCH, lds, gx);
   GemmP q = p; q.halo_lg = LG; q.halo_tw = TW; q.splitk = 1;
-  hipLaunchKernelGGL((conv_halo_kernel<BM, BN, LG>), dim3(gx), dim3(12 * 64), lds, s, q);
+  hipLaunchKernelGGL((conv_halo_kernel<BM, BN, LG, ST>), dim3(gx), dim3(12 * 64), lds, s, q);
 }
 
 void launch_conv_halo(const GemmP& p, int bm, int bn, hipStream_t s) {
   const int lg = halo_pick_lg(p, bm, bn);
   UG_REQUIRE(lg >= 0, "halo conv: no tile geometry");
+  if (p.stat_part) {   // (launch_gemm hands the statistics buffer only to the 128-column tiles)
+    UG_REQUIRE(bn == 128, "halo conv: epilogue statistics on 128-column tiles only");
+    if (bm == 192) launch_halo_t<192, 128, 4, true>(p, s);
+    else if (lg == 4) launch_halo_t<256, 128, 4, true>(p, s); else if (lg == 5) launch_halo_t<256, 128, 5, true>(p, s); else launch_halo_t<256, 128, 6, true>(p, s);
+    return;
+  }
   if (bm == 256 && bn == 160) launch_halo_t<256, 160, 5>(p, s);
   else if (bm == 256) { if (lg == 4) launch_halo_t<256, 128, 4>(p, s); else if (lg == 5) launch_halo_t<256, 128, 5>(p, s); else launch_halo_t<256, 128, 6>(p, s); }
   else if (bn == 160) launch_halo_t<192, 160, 4>(p, s);

@@ -56,7 +56,7 @@ template <int BM, int BN, int BK, int NST, int WMW, int WNW> struct GemmOcc {
 // loaders are byte movers, so an fp8 [rows][K] matrix is staged exactly like an fp16 [rows][K/2] one (the launcher halves K / lda /
 // ldw): a 128-byte LDS row is one 128-deep K step.  The block scales of a K step (one dword = 4 e8m0 per row) ride the same ring:
 // wave 0 / wave 1 fetch the A / W scale dwords of the tile's rows with one extra 1 KiB direct-to-LDS load each.
-template <int BM, int BN, int BK, int NST, int WMW, int WNW, bool CONV, bool UNI, bool BUFA = false, bool MX = false>
+template <int BM, int BN, int BK, int NST, int WMW, int WNW, bool CONV, bool UNI, bool BUFA = false, bool MX = false, bool ST = false>   // ST: statistics epilogue (GemmP::stat_part)
 __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>::wps)) void gemm_kernel(const GemmP p) {
   static_assert(!BUFA || !CONV || UNI, "buffer addressing needs the single-tap K tiles");
   static_assert(!MX || (!CONV && BK == 64 && BM <= 256 && BN <= 256), "MX path: dense, 128-byte K steps, <= 256 scale rows per operand");
@@ -402,7 +402,8 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
     // ---- tile finished: epilogue (the next tile's operands keep streaming into the ring meanwhile) ----
     drain = true;
     const int tile = wslot + ti * nwg;
-    { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn); tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
+    { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn);
+      if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm); else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
   }
 }
 
@@ -670,7 +671,7 @@ static bool gemm_can_bufa(const GemmP& p, int BK, bool packed) {
 // publishes step i+1 and frees slot i % 3.  Only producers ever have loads in flight in the K loop, so the epilogue's
 // global traffic (consumers) needs no drain logic.  LDS image, W row permutation, MFMA chain order and epilogue are those
 // of gemm_kernel: outputs are bit-identical.
-template <int BM, int BN, int WMW, int WNW, bool CONV>
+template <int BM, int BN, int WMW, int WNW, bool CONV, bool ST = false>   // ST: GroupNorm statistics of the output from the epilogue (GemmP::stat_part)
 __global__ __launch_bounds__((WMW * WNW + 4) * 64, 3) void gemm_ws_kernel(const GemmP p) {
   constexpr int NST = 3;
   constexpr int BK = 64;
@@ -890,7 +891,7 @@ __global__ __launch_bounds__((WMW * WNW + 4) * 64, 3) void gemm_ws_kernel(const 
     if (++cp_ks == nk) {
       cp_ks = 0;
       const int tile = wslot + (cp_ti++) * nwg;
-      { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn); tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
+      { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn); if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm); else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all fragment reads of this slot are done before it is handed back
     UG_STAMP(2);
@@ -926,6 +927,16 @@ static void launch_ws(const GemmP& p, int batch, hipStream_t s) {
   gx = (gx / 8) * 8;
   gx = std::min(gx, ntiles);
   dim3 grid(gx, split, batch);
+  if (p.stat_part) {   // launch_gemm: 128-column convolutions only
+    if constexpr (BN == 128) {
+      UG_REQUIRE(p.conv, "producer / consumer kernel: epilogue statistics for convolutions only");
+      static bool attrs[32] = {};
+      bool& ats = attrs[ug_dev_slot()];
+      if (!ats) { UG_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<BM, BN, WMW, WNW, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ats = true; }
+      hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, WMW, WNW, true, true>), grid, dim3((WMW * WNW + 4) * 64), lds, s, p);
+      return;
+    } else UG_REQUIRE(false, "producer / consumer kernel: epilogue statistics on 128-column tiles only");
+  }
   if (p.conv) hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, WMW, WNW, true>), grid, dim3((WMW * WNW + 4) * 64), lds, s, p);
   else hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, WMW, WNW, false>), grid, dim3((WMW * WNW + 4) * 64), lds, s, p);
 }
@@ -996,7 +1007,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue(const GemmP p) {
   }
 }
 
-template <int BM, int BN, int BK, int NST, int WMW, int WNW, bool CONV, bool UNI, bool BUFA = false>
+template <int BM, int BN, int BK, int NST, int WMW, int WNW, bool CONV, bool UNI, bool BUFA = false, bool ST = false>
 static void launch_t(const GemmP& p, int batch, hipStream_t s) {
   const int ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
 #ifdef UG_GEMM_TRACE
@@ -1004,7 +1015,7 @@ static void launch_t(const GemmP& p, int batch, hipStream_t s) {
 #else
   const size_t lds = (size_t)NST * (BM + BN) * BK * sizeof(f16);
 #endif
-  auto kern = gemm_kernel<BM, BN, BK, NST, WMW, WNW, CONV, UNI, BUFA>;
+  auto kern = gemm_kernel<BM, BN, BK, NST, WMW, WNW, CONV, UNI, BUFA, false, ST>;
   static bool attr[32] = {};
   bool& at = attr[ug_dev_slot()];
   if (!at) {
@@ -1034,6 +1045,10 @@ static void launch_mode(const GemmP& p, int batch, hipStream_t s) {
     const bool uni = kc_ok && ((p.C0 + p.C1) % BK) == 0 && (p.C0 % BK) == 0 && p.kt * p.ky * p.kx <= 32;
     const long px = (long)p.T * p.Hi * p.Wi + ((long)(p.kt >> 1) * p.Hi + p.pad_t) * p.Wi + p.pad_l + 1;
     const bool bufa = bufw && uni && p.ups == 1 && px * p.C0 * 2 < lim && px * p.C1 * 2 < lim;
+    if (p.stat_part) {   // launch_gemm: only for the one symmetric-kernel tile instantiated with the statistics epilogue (config 14, buffer-addressed im2col)
+      if constexpr (BM == 256 && BN == 64 && NST == 2 && WMW == 4) { UG_REQUIRE(uni && bufa, "statistics epilogue: buffer-addressed im2col only"); launch_t<BM, BN, BK, NST, WMW, WNW, true, true, true, true>(p, batch, s); return; }
+      else UG_REQUIRE(false, "statistics epilogue: tile not instantiated");
+    }
     if (uni && bufa) launch_t<BM, BN, BK, NST, WMW, WNW, true, true, true>(p, batch, s);
     else if (uni) launch_t<BM, BN, BK, NST, WMW, WNW, true, true>(p, batch, s);
     else launch_t<BM, BN, BK, NST, WMW, WNW, true, false>(p, batch, s);
@@ -1309,8 +1324,10 @@ static int pick_group_m(const GemmP& p, int cfg, int batch, int split) {
   return g;
 }
 
-void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
+void launch_gemm(const GemmP& p0, int batch, hipStream_t s, int* stat_rb) {
   GemmP p = p0;
+  if (stat_rb) *stat_rb = 0;
+  if (!stat_rb) p.stat_part = nullptr;
   if (p.tune_knobs & 2) p.flags |= UG_F_NOXCD;
   if (p.tune_knobs & 16) p.flags |= UG_F_PRIO;
   UG_REQUIRE(p.K % 8 == 0, "GEMM K must be a multiple of 8");
@@ -1347,7 +1364,8 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
       const int M1 = (int)(whole / ntn) * 256;
       const bool halo = false;                                    // (the halo kernel takes these convolutions as ONE launch on 256 x 128 tiles instead - below; knob 32768 = this row split, A/B)
       GemmP a = p; a.M = M1; a.cfg_p1 = 61;                     // config 60 (+ 1)
-      GemmP b = p0; b.M = p.M - M1; b.m_off = M1; b.Out = (void*)((f16*)p.Out + (long)M1 * p.ldo);
+      a.stat_part = nullptr;                                      // (two tile geometries for one tensor: no epilogue statistics)
+      GemmP b = p0; b.stat_part = nullptr; b.M = p.M - M1; b.m_off = M1; b.Out = (void*)((f16*)p.Out + (long)M1 * p.ldo);
       if (p.flags & UG_F_NOXCD) b.flags |= UG_F_NOXCD;
       if (b.R1) b.R1 += (long)M1 * p.ldr1;
       if (b.R2) b.R2 += (long)M1 * p.ldr2;
@@ -1397,6 +1415,28 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s) {
     switch (cfg) { case 0: case 1: case 3: bm = 128; break; case 12: bm = 64; break; case 61: case 62: case 63: case 64: bm = 192; break; default: break; }
     const long hw = (long)p.Ho * p.Wo;
     if (hw % bm == 0 && hw / bm >= 1) { p.tm_T = p.T; p.tm_nb = (int)(hw / bm); }
+  }
+  if (p.stat_part) {
+    // GroupNorm statistics of the output from the epilogue (GemmP::stat_part): one block per wave tile of WTM rows.  Only where every row of every tile
+    // is stored through the epilogue's fp16 vector path and the blocks do not straddle frames; otherwise the caller runs the statistics pass.  Knob 131072 = off.
+    int bm = 0, wmw = 0;
+    switch (cfg) {   // the kernels instantiated with the statistics epilogue: halo tiles of 128 columns, the producer / consumer tiles of 128 columns (convolutions)
+      case 71: bm = 256; wmw = 4; break;
+      case 72: bm = 192; wmw = 4; break;
+      case 14: if (p.conv && gemm_can_bufa(p, 64, false) && !(p.tune_knobs & 4)) { bm = 256; wmw = 4; } break;   // (the symmetric kernel: temporal convolutions onto <= 320 columns)
+      case 54: if (p.conv && gemm_can_bufa(p, 64, true)) { bm = 256; wmw = 4; } break;
+      case 59: if (p.conv && gemm_can_bufa(p, 64, true)) { bm = 256; wmw = 2; } break;
+      case 63: if (p.conv && gemm_can_bufa(p, 64, true)) { bm = 192; wmw = 2; } break;
+      case 64: if (p.conv && gemm_can_bufa(p, 64, true)) { bm = 192; wmw = 4; } break;
+      default: break;
+    }
+    const int wtm = bm ? bm / wmw : 0;
+    const bool ok = bm && split == 1 && batch == 1 && !(p.flags & (UG_F_GEGLU | UG_F_OUT_F32)) && !p.up_phase && !(p.tune_knobs & 131072) &&
+                    p.M % bm == 0 && p.m_off == 0 && p.stat_hw > 0 && p.stat_hw % wtm == 0 && p.N % 16 == 0 && p.ldo % 8 == 0 &&
+                    (!p.R1 || p.ldr1 % 8 == 0) && (!p.R2 || p.ldr2 % 8 == 0);
+    static const bool sdbg = getenv("UG_STAT_DEBUG") != nullptr;
+    if (sdbg) fprintf(stderr, "[stat] M %d N %d K %d conv %d kt %d hw %d cfg %d split %d -> rb %d\n", p.M, p.N, p.K, p.conv, p.kt, p.stat_hw, cfg, split, ok ? wtm : 0);
+    if (ok) *stat_rb = wtm; else p.stat_part = nullptr;
   }
   launch_cfg(cfg, p, batch, s);
   if (split > 1) {

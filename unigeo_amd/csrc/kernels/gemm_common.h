@@ -217,3 +217,86 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][N
   }
 }
 
+// sum over the 16 lanes of a DPP row (the lanes that hold the 16 rows of one MFMA block for the same columns): xor 1, xor 2 inside the quads,
+// then the mirrored half row and the mirrored row - every lane ends up with the total
+__device__ __forceinline__ float row16_sum(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, true));
+  return x;
+}
+
+// tile_epilogue for the launches that also hand GroupNorm its statistics (GemmP::stat_part, round 4): the wave's WTM rows are one statistics block
+// (index stat_blk); per 8-column chunk the rows are stored as tile_epilogue stores them (same arithmetic, same roundings - bit-identical outputs)
+// while the fp16 values written are summed per column (sum, sum of squares) in registers, reduced over the 16 row lanes and stored by lane 0 of each
+// column group: stat_part[stat_blk * N + n].  Chunk-outer instead of row-outer order: 16 accumulators instead of 2 x 16 beside the MFMA accumulators
+// (row-outer spills in the 256-row tiles).  launch_gemm sends a launch here only when every in-range lane would take tile_epilogue's fp16 vector
+// path: whole tiles, 8-aligned leading dimensions, N % 16 == 0, no GEGLU / fp32 output / fp32 residual / split-K / sub-pixel scatter.
+template <int MT, int NT, int WTM, int WTN>
+__device__ __forceinline__ void tile_epilogue_stats(const GemmP& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wm, int wn, int lane, int stat_blk) {
+  constexpr int WID = 4 * NT;
+  static_assert(WID % 8 == 0, "statistics epilogue: 8-column chunks");
+  const int l15 = lane & 15, g = lane >> 4;
+  const int nb = n0 + wn * WTN + g * WID;
+  const bool full = (nb + WID <= p.N);
+#pragma unroll
+  for (int e = 0; e < WID; e += 8) {
+    float bv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bv[q] = 0.f;
+    if (full) {
+      if (p.bias) { const f16x8 b = *(const f16x8*)(p.bias + nb + e);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bv[q] += (float)b[q]; }
+      if (p.bias2) { const f16x8 b = *(const f16x8*)(p.bias2 + nb + e);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bv[q] += (float)b[q]; }
+    }
+    float ssum[8], ssq[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { ssum[q] = 0.f; ssq[q] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      int m = m0 + wm * WTM + i * 16 + l15;
+      if (p.halo_tw) { const int r = wm * WTM + i * 16 + l15; m = m0 + (r >> p.halo_lg) * p.Wo + (r & (p.halo_tw - 1)); }
+      float o[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        o[q] = p.c0 * (acc[i][(e + q) >> 2][(e + q) & 3] + bv[q]);
+        acc[i][(e + q) >> 2][(e + q) & 3] = 0.f;
+      }
+      if (!full) continue;
+      if (p.R1) {
+        const f16x8 r = *(const f16x8*)(p.R1 + (long)m * p.ldr1 + nb + e);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] += p.c1 * (float)r[q];
+      }
+      if (p.R2) {
+        const f16x8 r = *(const f16x8*)(p.R2 + (long)m * p.ldr2 + nb + e);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] += p.c2 * (float)r[q];
+      }
+      if (p.act == UG_ACT_SILU) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = silu_f(o[q]);
+      } else if (p.act == UG_ACT_GELU) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = gelu_f(o[q]);
+      }
+      f16x8 h;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) h[q] = (f16)o[q];
+      *(f16x8*)((f16*)p.Out + (long)m * p.ldo + nb + e) = h;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const float f = (float)h[q]; ssum[q] += f; ssq[q] += f * f; }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { ssum[q] = row16_sum(ssum[q]); ssq[q] = row16_sum(ssq[q]); }
+    if (l15 == 0 && full) {
+      float2* dst = p.stat_part + (long)stat_blk * p.N + nb + e;
+#pragma unroll
+      for (int q = 0; q < 8; q += 2) *(f32x4*)(dst + q) = (f32x4){ssum[q], ssq[q], ssum[q + 1], ssq[q + 1]};
+    }
+  }
+}

@@ -155,6 +155,45 @@ __global__ __launch_bounds__(1024) void gn_finalize(const GroupNormP p, int nchu
   }
 }
 
+// phase 2 when the statistics come from the producing GEMM's epilogue (GroupNormP::part: per block of part_rb rows and per channel the sum / sum of
+// squares of the fp16 values stored): grid (G, temporal ? 1 : T) - workgroup (g, t) combines the blocks of its frame (all frames: pooled) x the
+// channels of its group in fp64, fixed order, and writes the scale / shift of the group's channels (pooled: for every frame).
+__global__ __launch_bounds__(1024) void gn_finalize_cols(const GroupNormP p, float* ab) {
+  __shared__ double sa[1024], sb[1024];
+  const int C = p.C0, cpg = C / p.G, g = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+  const int S = p.HW / p.part_rb;                              // blocks per frame
+  const int tlo = p.temporal ? 0 : blockIdx.y, thi = p.temporal ? p.T : blockIdx.y + 1;
+  const int nitem = (thi - tlo) * S * cpg;
+  const float2* src = p.part + (long)tlo * S * C + g * cpg;
+  double a = 0.0, b = 0.0;
+  auto at = [&](int it) { const int bs = it / cpg, cc = it - bs * cpg; return src[(long)bs * C + cc]; };
+  int it = tid;
+  for (; it + 3 * NT < nitem; it += 4 * NT) {                  // 4 independent loads in flight, fixed summation order
+    const float2 v0 = at(it), v1 = at(it + NT), v2 = at(it + 2 * NT), v3 = at(it + 3 * NT);
+    a += (double)v0.x; b += (double)v0.y; a += (double)v1.x; b += (double)v1.y;
+    a += (double)v2.x; b += (double)v2.y; a += (double)v3.x; b += (double)v3.y;
+  }
+  for (; it < nitem; it += NT) { const float2 v = at(it); a += (double)v.x; b += (double)v.y; }
+  sa[tid] = a; sb[tid] = b;
+  __syncthreads();
+  for (int st = NT / 2; st > 0; st >>= 1) {
+    if (tid < st) { sa[tid] += sa[tid + st]; sb[tid] += sb[tid + st]; }
+    __syncthreads();
+  }
+  const double n = (double)cpg * p.HW * (thi - tlo);
+  const double mean = sa[0] / n;
+  double var = sb[0] / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + (double)p.eps));
+  for (int i = tid; i < (thi - tlo) * cpg; i += NT) {
+    const int t = tlo + i / cpg, c = g * cpg + i % cpg;
+    const float ga = p.gamma ? (float)p.gamma[c] : 1.f, be = p.beta ? (float)p.beta[c] : 0.f;
+    const float sc = rf * ga;
+    ab[((long)t * C + c) * 2 + 0] = sc;
+    ab[((long)t * C + c) * 2 + 1] = be - mf * sc;
+  }
+}
+
 // phase 3 for workgroup (chunk, t): y = silu(x * a[c] + b[c]); coef(c, a, b) supplies the per-channel scale / shift
 template <typename F>
 __device__ __forceinline__ void gn_apply_body(const GroupNormP& p, int t, int chunk, int rows_per_chunk, F coef) {
@@ -487,6 +526,18 @@ void launch_groupnorm(const GroupNormP& p, hipStream_t s) {
   if (mode == 2 && !small_ok) mode = 1;
   if (mode == 3) mode = 1;   // (3 was round 3's one-launch ticket scheme: slower than three launches everywhere, removed in round 4)
   if (mode == 6 && !tnt) mode = 1;
+  if (p.part && p.mode == 0 && (mode == 1 || mode == 6)) {
+    // the producing GEMM's epilogue left per-block column sums (GemmP::stat_part): no statistics pass over X - combine them, apply
+    UG_REQUIRE(p.C1 == 0 && p.part_rb > 0 && p.HW % p.part_rb == 0, "GroupNorm: epilogue statistics need a single source and whole blocks per frame");
+    int nchunk, rpc;
+    gn_chunks2(p.T, p.HW, C, nchunk, rpc);
+    float* ab = p.ws + (size_t)p.T * nchunk * p.G * 2;
+    const long nitem = (long)(p.temporal ? p.T : 1) * (p.HW / p.part_rb) * cpg;
+    hipLaunchKernelGGL(gn_finalize_cols, dim3(p.G, p.temporal ? 1 : p.T), dim3(nitem > 2048 ? 1024 : 256), 0, s, p, ab);
+    hipLaunchKernelGGL(gn_apply, dim3(nchunk, p.T), dim3(GN_THREADS), 0, s, p, rpc, (const float*)ab);
+    UG_CHECK(hipGetLastError());
+    return;
+  }
   if (mode == 4) {
     gn_slab_launch<0>(p, snt, svmax, dim3(p.G, p.temporal ? 1 : p.T), s);
   } else if (mode == 6) {
