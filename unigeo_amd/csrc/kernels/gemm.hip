@@ -1431,7 +1431,7 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s, int* stat_rb) {
       default: break;
     }
     const int wtm = bm ? bm / wmw : 0;
-    const bool ok = bm && split == 1 && batch == 1 && !(p.flags & (UG_F_GEGLU | UG_F_OUT_F32)) && !p.up_phase && !(p.tune_knobs & 131072) &&
+    const bool ok = bm && split == 1 && batch == 1 && !(p.flags & (UG_F_GEGLU | UG_F_OUT_F32 | UG_F_R1_F32)) && !p.up_phase && !(p.tune_knobs & 131072) &&
                     p.M % bm == 0 && p.m_off == 0 && p.stat_hw > 0 && p.stat_hw % wtm == 0 && p.N % 16 == 0 && p.ldo % 8 == 0 &&
                     (!p.R1 || p.ldr1 % 8 == 0) && (!p.R2 || p.ldr2 % 8 == 0);
     static const bool sdbg = getenv("UG_STAT_DEBUG") != nullptr;
