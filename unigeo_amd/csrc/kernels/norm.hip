@@ -158,11 +158,15 @@ __global__ __launch_bounds__(1024) void gn_finalize(const GroupNormP p, int nchu
 // phase 2 when the statistics come from the producing GEMM's epilogue (GroupNormP::part: per block of part_rb rows and per channel the sum / sum of
 // squares of the fp16 values stored): grid (G, temporal ? 1 : T) - workgroup (g, t) combines the blocks of its frame (all frames: pooled) x the
 // channels of its group in fp64, fixed order, and writes the scale / shift of the group's channels (pooled: for every frame).
-__global__ __launch_bounds__(1024) void gn_finalize_cols(const GroupNormP p, float* ab) {
+// FRAME_PART (pooled statistics over many blocks - the VAE decoder's 196608-pixel frames): the workgroup of frame t only writes its (sum, sum of squares)
+// to scratch[t * G + g]; gn_finalize_pool combines the T entries.  One stage: 32 workgroups x 98 K items = 72 us; two: 12 + 5.
+template <bool FRAME_PART>
+__global__ __launch_bounds__(1024) void gn_finalize_cols(const GroupNormP p, float* ab, double2* scratch) {
   __shared__ double sa[1024], sb[1024];
   const int C = p.C0, cpg = C / p.G, g = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
   const int S = p.HW / p.part_rb;                              // blocks per frame
-  const int tlo = p.temporal ? 0 : blockIdx.y, thi = p.temporal ? p.T : blockIdx.y + 1;
+  const bool pooled = p.temporal && !FRAME_PART;
+  const int tlo = pooled ? 0 : blockIdx.y, thi = pooled ? p.T : blockIdx.y + 1;
   const int nitem = (thi - tlo) * S * cpg;
   const float2* src = p.part + (long)tlo * S * C + g * cpg;
   double a = 0.0, b = 0.0;
@@ -180,6 +184,10 @@ __global__ __launch_bounds__(1024) void gn_finalize_cols(const GroupNormP p, flo
     if (tid < st) { sa[tid] += sa[tid + st]; sb[tid] += sb[tid + st]; }
     __syncthreads();
   }
+  if (FRAME_PART) {
+    if (tid == 0) scratch[(long)blockIdx.y * p.G + g] = make_double2(sa[0], sb[0]);
+    return;
+  }
   const double n = (double)cpg * p.HW * (thi - tlo);
   const double mean = sa[0] / n;
   double var = sb[0] / n - mean * mean;
@@ -187,6 +195,24 @@ __global__ __launch_bounds__(1024) void gn_finalize_cols(const GroupNormP p, flo
   const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + (double)p.eps));
   for (int i = tid; i < (thi - tlo) * cpg; i += NT) {
     const int t = tlo + i / cpg, c = g * cpg + i % cpg;
+    const float ga = p.gamma ? (float)p.gamma[c] : 1.f, be = p.beta ? (float)p.beta[c] : 0.f;
+    const float sc = rf * ga;
+    ab[((long)t * C + c) * 2 + 0] = sc;
+    ab[((long)t * C + c) * 2 + 1] = be - mf * sc;
+  }
+}
+// second stage of the pooled form: grid (G), one wave - frame sums in fixed order, scale / shift of the group's channels for every frame
+__global__ __launch_bounds__(64) void gn_finalize_pool(const GroupNormP p, const double2* scratch, float* ab) {
+  const int C = p.C0, cpg = C / p.G, g = blockIdx.x, tid = threadIdx.x;
+  double a = 0.0, b = 0.0;
+  for (int t = 0; t < p.T; ++t) { const double2 v = scratch[(long)t * p.G + g]; a += v.x; b += v.y; }
+  const double n = (double)cpg * p.HW * p.T;
+  const double mean = a / n;
+  double var = b / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + (double)p.eps));
+  for (int i = tid; i < p.T * cpg; i += 64) {
+    const int t = i / cpg, c = g * cpg + i % cpg;
     const float ga = p.gamma ? (float)p.gamma[c] : 1.f, be = p.beta ? (float)p.beta[c] : 0.f;
     const float sc = rf * ga;
     ab[((long)t * C + c) * 2 + 0] = sc;
@@ -533,7 +559,14 @@ void launch_groupnorm(const GroupNormP& p, hipStream_t s) {
     gn_chunks2(p.T, p.HW, C, nchunk, rpc);
     float* ab = p.ws + (size_t)p.T * nchunk * p.G * 2;
     const long nitem = (long)(p.temporal ? p.T : 1) * (p.HW / p.part_rb) * cpg;
-    hipLaunchKernelGGL(gn_finalize_cols, dim3(p.G, p.temporal ? 1 : p.T), dim3(nitem > 2048 ? 1024 : 256), 0, s, p, ab);
+    const long per_frame = (long)(p.HW / p.part_rb) * cpg;
+    if (p.temporal && p.T > 1 && per_frame >= 8192 && (size_t)p.T * p.G * 4 <= (size_t)p.T * nchunk * p.G * 2) {   // pooled over many blocks: per-frame sums, then one wave per group
+      double2* scratch = (double2*)p.ws;
+      hipLaunchKernelGGL(gn_finalize_cols<true>, dim3(p.G, p.T), dim3(1024), 0, s, p, ab, scratch);
+      hipLaunchKernelGGL(gn_finalize_pool, dim3(p.G), dim3(64), 0, s, p, (const double2*)scratch, ab);
+    } else {
+      hipLaunchKernelGGL(gn_finalize_cols<false>, dim3(p.G, p.temporal ? 1 : p.T), dim3(nitem > 2048 ? 1024 : 256), 0, s, p, ab, (double2*)nullptr);
+    }
     hipLaunchKernelGGL(gn_apply, dim3(nchunk, p.T), dim3(GN_THREADS), 0, s, p, rpc, (const float*)ab);
     UG_CHECK(hipGetLastError());
     return;
