@@ -560,7 +560,7 @@ void launch_groupnorm(const GroupNormP& p, hipStream_t s) {
     float* ab = p.ws + (size_t)p.T * nchunk * p.G * 2;
     const long nitem = (long)(p.temporal ? p.T : 1) * (p.HW / p.part_rb) * cpg;
     const long per_frame = (long)(p.HW / p.part_rb) * cpg;
-    if (p.temporal && p.T > 1 && per_frame >= 8192 && (size_t)p.T * p.G * 4 <= (size_t)p.T * nchunk * p.G * 2) {   // pooled over many blocks: per-frame sums, then one wave per group
+    if (p.temporal && p.T > 1 && per_frame >= 2048 && (size_t)p.T * p.G * 4 <= (size_t)p.T * nchunk * p.G * 2) {   // pooled over many blocks: per-frame sums, then one wave per group
       double2* scratch = (double2*)p.ws;
       hipLaunchKernelGGL(gn_finalize_cols<true>, dim3(p.G, p.T), dim3(1024), 0, s, p, ab, scratch);
       hipLaunchKernelGGL(gn_finalize_pool, dim3(p.G), dim3(64), 0, s, p, (const double2*)scratch, ab);
