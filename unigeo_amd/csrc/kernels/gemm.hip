@@ -418,7 +418,7 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
 // their fragment reads and MFMAs, so the matrix pipe runs the partner's K-step while the loader is queued on the
 // address path, and the loader's K-step afterwards.  Same LDS image, ring, barrier and MFMA order as gemm_kernel
 // (outputs are bit-identical).
-template <int BM, int BN, int NST, int WMW, int WNW, bool CONV>
+template <int BM, int BN, int NST, int WMW, int WNW, bool CONV, bool ST = false>   // ST: statistics epilogue (GemmP::stat_part)
 __global__ __launch_bounds__(512, 2) void gemm_ldr_kernel(const GemmP p) {
   constexpr int BK = 64;
   static_assert(WMW * WNW == 8, "two waves per SIMD");
@@ -635,7 +635,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ldr_kernel(const GemmP p) {
     cp_ks = 0;
     const int tile = wslot + (cp_ti++) * nwg;
     drain = true;
-    { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn); tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
+    { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn);
+      if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm); else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
   }
 }
 
@@ -963,6 +964,16 @@ static void launch_ldr(const GemmP& p, int batch, hipStream_t s) {
   gx = (gx / 8) * 8;
   gx = std::min(gx, ntiles);
   dim3 grid(gx, split, batch);
+  if (p.stat_part) {   // launch_gemm: the 256 x 256 im2col tile only (config 35: the wide temporal convolutions of the VAE decoder)
+    if constexpr (BM == 256 && BN == 256) {
+      UG_REQUIRE(p.conv, "loader kernel: epilogue statistics for convolutions only");
+      static bool attrs[32] = {};
+      bool& ats = attrs[ug_dev_slot()];
+      if (!ats) { UG_CHECK(hipFuncSetAttribute((const void*)gemm_ldr_kernel<BM, BN, NST, WMW, WNW, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ats = true; }
+      hipLaunchKernelGGL((gemm_ldr_kernel<BM, BN, NST, WMW, WNW, true, true>), grid, dim3(512), lds, s, p);
+      return;
+    } else UG_REQUIRE(false, "loader kernel: epilogue statistics on the 256 x 256 tile only");
+  }
   if (p.conv) hipLaunchKernelGGL((gemm_ldr_kernel<BM, BN, NST, WMW, WNW, true>), grid, dim3(512), lds, s, p);
   else hipLaunchKernelGGL((gemm_ldr_kernel<BM, BN, NST, WMW, WNW, false>), grid, dim3(512), lds, s, p);
 }
@@ -1045,8 +1056,8 @@ static void launch_mode(const GemmP& p, int batch, hipStream_t s) {
     const bool uni = kc_ok && ((p.C0 + p.C1) % BK) == 0 && (p.C0 % BK) == 0 && p.kt * p.ky * p.kx <= 32;
     const long px = (long)p.T * p.Hi * p.Wi + ((long)(p.kt >> 1) * p.Hi + p.pad_t) * p.Wi + p.pad_l + 1;
     const bool bufa = bufw && uni && p.ups == 1 && px * p.C0 * 2 < lim && px * p.C1 * 2 < lim;
-    if (p.stat_part) {   // launch_gemm: only for the one symmetric-kernel tile instantiated with the statistics epilogue (config 14, buffer-addressed im2col)
-      if constexpr (BM == 256 && BN == 64 && NST == 2 && WMW == 4) { UG_REQUIRE(uni && bufa, "statistics epilogue: buffer-addressed im2col only"); launch_t<BM, BN, BK, NST, WMW, WNW, true, true, true, true>(p, batch, s); return; }
+    if (p.stat_part) {   // launch_gemm: only for the symmetric-kernel tiles instantiated with the statistics epilogue (configs 14 and 19, buffer-addressed im2col)
+      if constexpr ((BM == 256 && BN == 64 && NST == 2 && WMW == 4) || (BM == 256 && BN == 128 && NST == 3 && WMW == 2)) { UG_REQUIRE(uni && bufa, "statistics epilogue: buffer-addressed im2col only"); launch_t<BM, BN, BK, NST, WMW, WNW, true, true, true, true>(p, batch, s); return; }
       else UG_REQUIRE(false, "statistics epilogue: tile not instantiated");
     }
     if (uni && bufa) launch_t<BM, BN, BK, NST, WMW, WNW, true, true, true>(p, batch, s);
@@ -1214,7 +1225,7 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
     else if (!p.conv && !geglu && cfg == 63 && p.K >= 2048 && p.N <= 1280) cfg = 64;                          // 19200x640x2560: 74 vs 79; 4800x1280x5120: 66 vs 69
     else if (!p.conv && !geglu && p.M >= 50000 && p.K <= 384 && p.N >= 640 && p.N < 2048 && bufa) cfg = 59;  // 76800x960x320 (Q|K|V): 77 vs 85
     else if (!p.conv && !geglu && p.N <= 384 && p.K >= 1024 && p.M > 2048 && p.M <= 16384) cfg = 3;          // tail rows 11264x320x1280: 23.8 vs 28.0
-    else if (p.conv && p.kt > 1 && p.N <= 320 && p.M >= 50000) cfg = 14;                                      // temporal conv 76800x320x960: 80 vs 90
+    else if (p.conv && p.kt > 1 && p.N > 256 && p.N <= 320 && p.M >= 50000 && !(p.tune_knobs & 524288)) cfg = 14;   // temporal conv 76800x320x960: 80 vs 90 (NOT the VAE decoder's 256- / 128-column ones: 393216x256x768 299 vs 228 on the cost model's tile; knob 524288 = the rule off, A/B)
   }
   int split = 1;
   const long tiles128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128) * batch;
@@ -1424,6 +1435,8 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s, int* stat_rb) {
       case 71: bm = 256; wmw = 4; break;
       case 72: bm = 192; wmw = 4; break;
       case 14: if (p.conv && gemm_can_bufa(p, 64, false) && !(p.tune_knobs & 4)) { bm = 256; wmw = 4; } break;   // (the symmetric kernel: temporal convolutions onto <= 320 columns)
+      case 19: if (p.conv && gemm_can_bufa(p, 64, false) && !(p.tune_knobs & 4)) { bm = 256; wmw = 2; } break;   // (... and onto 128 columns at the VAE decoder's full resolution)
+      case 35: if (p.conv && gemm_can_bufa(p, 64, true)) { bm = 256; wmw = 2; } break;                             // loader kernel, 256 x 256 tile
       case 54: if (p.conv && gemm_can_bufa(p, 64, true)) { bm = 256; wmw = 4; } break;
       case 59: if (p.conv && gemm_can_bufa(p, 64, true)) { bm = 256; wmw = 2; } break;
       case 63: if (p.conv && gemm_can_bufa(p, 64, true)) { bm = 192; wmw = 2; } break;
