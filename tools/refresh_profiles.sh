@@ -1,3 +1,5 @@
+#!/bin/bash
+# usage (through gpurun): bash tools/refresh_profiles.sh  -> gpurun_out/r04_*; copy what is to be judged into profiles/
 # final round-4 measurement refresh: default bench line, rocprofv3 kernel stats of the same workload, PMC traffic / MFMA utilisation, per-shape table
 python bench.py > gpurun_out/r04_bench_line_final.json 2> gpurun_out/r04_bench_final.err; tail -c 600 gpurun_out/r04_bench_line_final.json
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
