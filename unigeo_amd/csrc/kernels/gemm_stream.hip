@@ -24,9 +24,8 @@
 template <int NSLOT, int NF>   // ring slots, fetch waves (each loads 20 / NF KiB of a tile: vmcnt counts <= 63 loads)
 __global__ __launch_bounds__((5 + NF) * 64, 2) void gemm_stream320_kernel(const GemmP p, int ngroups, int wg_per_group) {
   constexpr int BM = 32, KT = 5, NCW = 5;
-  constexpr int LEAD = 0;                            // tile i + LEAD has landed at the barrier that starts iteration i
   constexpr int LPT = 20 / NF;                       // loads per fetch wave per tile
-  static_assert((NSLOT - 2) * LPT <= 63 && NSLOT * 20 <= 160 && NSLOT >= 3 + LEAD, "vmcnt range / LDS");
+  static_assert((NSLOT - 2) * LPT <= 63 && NSLOT * 20 <= 160 && NSLOT >= 3, "vmcnt range / LDS");
   constexpr int TILE = KT * BM * 64;                 // halves per activation tile: [KT][32 rows][64]
   constexpr unsigned SENT = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) f16 ring[];   // [NSLOT][TILE] = 80 KiB
@@ -61,12 +60,11 @@ __global__ __launch_bounds__((5 + NF) * 64, 2) void gemm_stream320_kernel(const 
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(dst + (kt * BM + j * 8) * 64), 16, ok ? (int)roff[jj] : (int)SENT, (m0 * p.C0 + kt * 64) * 2, 0, 0);
         }
     };
-    // NSLOT - 1 tiles issued ahead; tile it + LEAD must have landed before the barrier that starts iteration it (it = -LEAD: the LayerNorm waves'
-    // first tile)
+    // NSLOT - 1 tiles issued ahead; tile it must have landed before the barrier that starts iteration it
     for (int t = 0; t < NSLOT - 1 && t < my_tiles; ++t) issue(t);
-    for (int it = -LEAD; it < my_tiles; ++it) {
-      // younger tiles that may still be in flight behind tile it + LEAD: issued so far = up to it + NSLOT - 2
-      const int younger = max(0, min(it + NSLOT - 2, my_tiles - 1) - (it + LEAD));
+    for (int it = 0; it < my_tiles; ++it) {
+      // younger tiles that may still be in flight behind tile it: issued so far = up to it + NSLOT - 2
+      const int younger = max(0, min(it + NSLOT - 2, my_tiles - 1) - it);
       switch (younger) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory"); break;
@@ -76,8 +74,8 @@ __global__ __launch_bounds__((5 + NF) * 64, 2) void gemm_stream320_kernel(const 
         case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * LPT <= 63 ? 5 * LPT : 63) : "memory"); break;
         default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * LPT <= 63 ? 6 * LPT : 63) : "memory"); break;
       }
-      __builtin_amdgcn_s_barrier();                  // publishes tile it + LEAD; everybody has left the slot of tile it - 1
-      if (it >= 0 && it + NSLOT - 1 < my_tiles) issue(it + NSLOT - 1);   // into the slot of tile it - 1
+      __builtin_amdgcn_s_barrier();                  // publishes tile it; everybody has left the slot of tile it - 1
+      if (it + NSLOT - 1 < my_tiles) issue(it + NSLOT - 1);   // into the slot of tile it - 1
     }
     return;
   }
