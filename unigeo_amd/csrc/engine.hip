@@ -927,7 +927,8 @@ struct PreNorm { const f16* g; const f16* b; float eps; const f16* addvec; long 
 // keeps 88 CUs busy while 168 wait.  Rows that would fall into such a thin last round (<= 160 tiles) go through the two-GEMM path
 // instead - the fused kernel then runs whole rounds only (ff_fused_rows).  (Round 4 ran those rows through the same kernel on 64-row tiles, 176 tiles on
 // 176 CUs: 59.9 us against 55.2 + the LayerNorm launch for 11264 rows, bit-identical, 961.7 vs 961.1 ms per clip - every workgroup streams the whole
-// 4.9 MB of W1 | W2 whatever its row count, so halving the rows does not halve the tile.  No gain, removed.)
+// 4.9 MB of W1 | W2 whatever its row count, so halving the rows does not halve the tile.  No gain, removed.  Likewise a persistent grid of 200 workgroups
+// x 3 tiles instead of 256 x 2 + the tail launches: 951.5 against 944 ms per clip - a tile costs the same whether 200 or 256 run beside it.)
 static long ff_fused_rows(long M) {
   const long ntile = (M + 127) / 128, full = ntile / 256 * 256, rem = ntile - full;
   return (full > 0 && rem > 0 && rem <= 160 && !getenv("UG_FF_NOSPLIT")) ? full * 128 : M;
