@@ -583,6 +583,26 @@ def test_groupnorm_statistics_from_conv_epilogue(engine, T, H, W, C, O, kt, k, t
     assert (d > 0).mean() < 0.02, f"epilogue vs pass statistics: {(d > 0).mean():.3%} of the elements differ"
 
 
+@pytest.mark.parametrize("cfg,want_rb", [(14, 64), (19, 128), (35, 128), (54, 64), (59, 128), (63, 96), (64, 48)])
+def test_statistics_epilogue_on_every_instantiated_tile(engine, cfg, want_rb):
+    """Every general tile that is instantiated with the statistics epilogue, forced on one temporal convolution (the planner would pick one of them):
+    block size as documented, convolution output unchanged (checked inside the op), GroupNorm equal to the statistics-pass form."""
+    rng = np.random.default_rng(cfg)
+    T, H, W, C = 4, 96, 128, 256
+    x = rnd(rng, T, H, W, C)
+    w = rnd(rng, C, C, 3, 1, 1, scale=(3 * C) ** -0.5)
+    b, r = rnd(rng, C), rnd(rng, T, H, W, C)
+    gamma, beta = h16(1.0 + 0.2 * rng.standard_normal(C)), h16(0.1 * rng.standard_normal(C))
+    try:
+        engine.tune_force(cfg, 1)
+        co, y_pass, y_epi, rb = engine.op_conv_gn(x, w, b, 32, 1e-5, gamma, beta, res=r, kt=3, k=1, temporal=True)
+    finally:
+        engine.tune_force(-1, -1)
+    assert rb == want_rb, f"config {cfg}: rows per statistics block {rb}, expected {want_rb}"
+    d = np.abs(y_epi - y_pass)
+    assert d.max() <= 4e-3 * max(1.0, float(np.abs(y_pass).max())) and (d > 0).mean() < 0.02, f"config {cfg}: max diff {d.max()}, {(d > 0).mean():.3%} differ"
+
+
 @pytest.mark.parametrize("C1", [0, 320])
 def test_conv_row_split_bitwise_full_size(engine, C1):
     """3x3 convolution onto 320 channels at the clip's level-0 size (25 x 48 x 64 = 76800 rows): launch_gemm runs the rows of the whole rounds
