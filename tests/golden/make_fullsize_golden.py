@@ -49,8 +49,15 @@ def main():
     ap.add_argument("--frames", type=int, default=25)
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=512)
-    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "fullsize_25step_golden.npz"))
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--fp16-storage", action="store_true",
+                    help="fp16-storage emulation of the reference's fp16 run (round 5): every leaf module of the UNet / CLIP tower / VAE decoder rounds "
+                         "its output to fp16 (tests/util.py: fp16_storage), the VAE encoder stays float32 (diffusers force_upcast), and the latents / "
+                         "scaled model input / v*c of the Euler step are rounded to fp16 where diffusers' fp16 pipeline rounds them; writes "
+                         "fullsize_25step_fp16emu_golden.npz")
     a = ap.parse_args()
+    if a.out is None:
+        a.out = os.path.join(ROOT, "tests", "golden", "fullsize_25step_fp16emu_golden.npz" if a.fp16_storage else "fullsize_25step_golden.npz")
     import torch
     torch.set_num_threads(a.threads)
     from oracle.geometry import prepare_output
@@ -74,7 +81,28 @@ def main():
     nl, na = make_noise(T, H, Wd, seed=0)
     tm = {}
     t0 = time.time()
-    fr, st = run_pipeline(unet, vae, clip, frames, torch.from_numpy(nl), torch.from_numpy(na), steps=a.steps, return_stages=True, timing=tm)
+    if a.fp16_storage:
+        import contextlib
+        import oracle.pipeline as OP
+        from oracle.scheduler import EulerKarrasVPred
+        from util import fp16_storage
+
+        class Fp16LatentEuler(EulerKarrasVPred):
+            """The scheduler as an fp16 pipeline sees it: fp16 latents in and out, fp16 `v * c` (oracle/scheduler.py: step)."""
+            def scale_model_input(self, sample, i):
+                return super().scale_model_input(sample.half(), i).half().float()
+
+            def step(self, model_output, i, sample):
+                return super().step(model_output.half(), i, sample.half()).float()
+
+        OP.EulerKarrasVPred = Fp16LatentEuler
+        ctx = fp16_storage(unet, clip, vae.decoder)
+        nl = nl.astype(np.float16).astype(np.float32)
+    else:
+        import contextlib
+        ctx = contextlib.nullcontext()
+    with ctx:
+        fr, st = run_pipeline(unet, vae, clip, frames, torch.from_numpy(nl), torch.from_numpy(na), steps=a.steps, return_stages=True, timing=tm)
     print(f"oracle pipeline: {time.time() - t0:.0f} s  {tm}", flush=True)
     per = np.stack([x.numpy() for x in st["latents_per_step"]], 0).astype(np.float64)        # [steps,T,4,h,w]
     keep = sorted({min(a.steps - 1, i) for i in (0, a.steps // 2, a.steps - 2)})
@@ -101,6 +129,7 @@ def main():
         metric_names=np.array(["Abs Rel", "delta < 1.25", "normal mean", "normal median"]),
         metrics=np.array([md["Abs Rel"], md["delta < 1.25"], mn["normal mean"], mn["normal median"]], np.float64),
         geometry=np.array([T, H, Wd, a.steps]), seeds=np.array([42, 1234, 0]),
+        fp16_storage=np.int64(1 if a.fp16_storage else 0),
         oracle_seconds=np.array([tm.get(k, 0.0) for k in ("clip_s", "vae_encode_s", "unet_s", "vae_decode_s")]), oracle_threads=np.int64(a.threads))
     print("wrote", a.out, os.path.getsize(a.out), "bytes; metrics", md["Abs Rel"], mn["normal mean"], flush=True)
 

@@ -547,7 +547,7 @@ def test_conv_halo_bitwise_and_reference(engine, T, H, W, C0, C1, O):
     (25, 24, 32, 640, 640, 1, 3, True, True, 48),      # ... + residual, statistics pooled over the frames (the temporal block's first GroupNorm)
     (25, 48, 64, 320, 320, 1, 3, False, False, 64),    # level 0, halo kernel on 256 x 128 tiles (three column tiles, the third half empty)
     (25, 24, 32, 640, 640, 3, 1, True, True, -1),      # temporal convolution on the producer / consumer kernel (48- or 96-row blocks by wave layout)
-    (25, 12, 16, 1280, 1280, 1, 3, False, True, 48),   # level 2: statistics written, GroupNorm keeps its one-launch slab form there
+    (25, 12, 16, 1280, 1280, 1, 3, False, True, 0),    # level 2: GroupNorm keeps its one-launch slab form there and ignores the partial sums - reported as 0 (round 5: launch_groupnorm says whether it consumed them)
     (2, 96, 128, 128, 128, 1, 3, False, False, 48),    # VAE decoder geometry
     (8, 96, 128, 512, 512, 3, 1, True, True, 128),     # VAE decoder temporal convolution on the 256 x 256 loader tile: 128-row blocks
     (2, 192, 256, 128, 128, 3, 1, True, False, -1),    # ... onto 128 columns (symmetric 256 x 128 or 256 x 64 tile by the planner's choice)

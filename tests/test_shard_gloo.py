@@ -83,6 +83,24 @@ def test_sharded_run_world8_ragged_tail():
         assert len(set(slices)) == world                                    # distinct slices when the host has >= world cores
 
 
+def test_affinity_plan_physical_cores_per_numa_node():
+    """ranks must not land on SMT siblings of each other's cores, must sit on their GPU's socket, and the divisor is the number of
+    ranks on THIS host.  Synthetic 2-socket host, 8 physical cores per socket, Linux SMT numbering (sibling of cpu c is c + 16)."""
+    from unigeo_amd.shard import plan_affinity
+    topo = {0: [[c, c + 16] for c in range(0, 8)], 1: [[c, c + 16] for c in range(8, 16)]}
+    gpu_nodes = [0, 0, 1, 1, 1, 1, 0, 0]                                   # GPUs 2-5 hang off socket 1
+    plans = [plan_affinity(r, 8, topo, gpu_nodes) for r in range(8)]
+    assert all(len(p) == 4 for p in plans)                                  # 2 physical cores x 2 hyperthreads each
+    assert len(set(c for p in plans for c in p)) == 32                      # disjoint, the whole host used
+    for r, p in enumerate(plans):
+        node_cpus = {c for core in topo[gpu_nodes[r]] for c in core}
+        assert set(p) <= node_cpus                                          # on the GPU's own socket
+        assert {c % 16 for c in p} == {c % 16 for c in p if c < 16}        # whole physical cores: both siblings or neither
+    # unknown GPU placement: ranks spread over the sockets in order; more ranks than cores: still one core each
+    assert plan_affinity(0, 2, topo) == sorted(c for core in topo[0] for c in core) and plan_affinity(1, 2, topo) == sorted(c for core in topo[1] for c in core)
+    assert plan_affinity(5, 8, {0: [[0], [1]]}) == [1]
+
+
 def test_partition_helpers():
     assert clips_for_rank(10, 8, 1) == [1, 9] and clips_for_rank(3, 8, 5) == []
     assert rounds(17, 8) == 3 and rounds(8, 8) == 1

@@ -14,7 +14,7 @@ for M, C in [(76800, 320), (19200, 320), (8192, 320), (76800, 256), (76800, 128)
           f"two launches {b:8.1f} us {fl / b / 1e6:7.0f} TF/s | x{b / ax:.2f}", flush=True)
 
 if len(sys.argv) > 1 and sys.argv[1] == "ablate":
-    # (needs the experiments build: make -C unigeo_amd/csrc experiments)  Where does a packet's time go?  Timing-only variants of the round-2 kernel with one ingredient removed (results are wrong by design).
+    # (needs the experiments build: make -C unigeo_amd/csrc experiments; UG_LIB_PATH=unigeo_amd/csrc/build/exp/libunigeo_exp.so)  Where does a packet's time go?  Timing-only variants of the round-2 kernel with one ingredient removed (results are wrong by design).
     M, C = 76800, 320
     names = {0: "full kernel", 1: "no GEGLU arithmetic", 2: "no weight-packet loads", 4: "no MFMAs", 8: "no fragment reads", 16: "no per-packet barrier",
              3: "no GEGLU, no loads", 10: "no loads, no fragment reads", 12: "no MFMAs, no fragment reads", 14: "loads off, MFMAs off, reads off", 18: "no loads, no barrier",

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """A/B of flash-attention variants on the clip's shapes (device-resident random data).
 variant bits: 1 = one softmax step per 64 keys, 2 = XCD-grouped workgroup order, 4 = 2-slot ring + 4 workgroups per CU, 16 = lazy rescale + dot2 row sums (23 = default),
-64 = 8-wave ping-pong kernel (87; + 128: priority flipped per phase, + 256: no priority).  `ablate` (experiments build: make -C unigeo_amd/csrc experiments): timing-only ablations of variant 7; `one`: the level-0 shape only (profiler runs)."""
+64 = 8-wave ping-pong kernel (87; + 128: priority flipped per phase, + 256: no priority).  `ablate` (experiments build: make -C unigeo_amd/csrc experiments; UG_LIB_PATH=unigeo_amd/csrc/build/exp/libunigeo_exp.so): timing-only ablations of variant 7; `one`: the level-0 shape only (profiler runs)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unigeo_amd._lib import Engine

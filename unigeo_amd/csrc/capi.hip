@@ -127,7 +127,7 @@ int ug_dc_run_windows(ug_ctx* x, int steps, int chunk, int with_normals, int win
 }
 int ug_set_ff_fused(ug_ctx* x, int on) {
   if (!x) return -1;
-  x->c.ff_fused = on & 3; x->c.lane_need.clear();   // (a feature toggle changes the transient memory a lane task needs)   // bit 0: fused feed-forward kernel, bit 1: its pre-LayerNorm inside the kernel, bit 2: fused LayerNorm -> Q|K|V projection
+  x->c.ff_fused = on & 3; x->c.lane_need.clear();   // bit 0: fused feed-forward kernel, bit 1: its pre-LayerNorm inside the kernel  (a feature toggle changes the transient memory a lane task needs) LayerNorm -> Q|K|V projection
   return 0;
 }
 int ug_set_fp8_linears(ug_ctx* x, int on) {
@@ -727,7 +727,8 @@ int ug_op_conv_gn(ug_ctx* x, const float* x0, int C0, int T, int H, int W, const
       g.X0 = pass ? o2 : o1; g.C0 = O; g.T = T; g.HW = H * W; g.G = G; g.eps = eps; g.temporal = temporal; g.silu = 1; g.gamma = dg; g.beta = dbt;
       g.Y = pass ? y2 : y1; g.ws = c.ws.get<float>((long)groupnorm_ws_floats(T, H * W, O, G));
       if (pass && rb > 0) { g.part = part; g.part_rb = rb; }
-      launch_groupnorm(g, c.stream);
+      const bool used = launch_groupnorm(g, c.stream);
+      if (pass && !used) rb = 0;              // the convolution wrote partial sums but GroupNorm took its slab / small form: report "no epilogue statistics"
       c.ws.release(mk);
     }
     *rb_out = rb;

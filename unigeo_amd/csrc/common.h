@@ -44,6 +44,7 @@ static inline int ug_dev_slot() { int d = 0; (void)hipGetDevice(&d); return d & 
 // ---------------------------------------------------------------------------------------
 enum { UG_ACT_NONE = 0, UG_ACT_SILU = 1, UG_ACT_GELU = 2 };
 enum { UG_F_GEGLU = 1, UG_F_OUT_F32 = 2, UG_F_NOXCD = 4, UG_F_PRIO = 8 /* tuning knob: static priority for the younger half of an 8-wave workgroup */,
+       UG_F_XCDROUND = 32 /* tuning knob 128: the round-strided XCD tile walk of rounds 1 - 4 (kernels/gemm_common.h: tile_walk) */,
        UG_F_R1_F32 = 16 /* R1 points at float32 (ldr1 in floats): the residual stream of the float32-grade VAE encoder, added in the epilogue instead of by a separate pass */ };
 
 struct GemmP {
@@ -134,7 +135,8 @@ struct GroupNormP {
   // gn_finalize_cols + gn_apply, no pass over X for the statistics
   const float2* part; int part_rb;
 };
-void launch_groupnorm(const GroupNormP& p, hipStream_t s);
+bool launch_groupnorm(const GroupNormP& p, hipStream_t s);                 // true = the statistics came from p.part (no pass over X for them)
+bool groupnorm_uses_part(const GroupNormP& p, int part_rb);                // the launcher's rule for that, for the callers that decide whether a producer writes partial sums
 size_t groupnorm_ws_floats(int T, int HW, int C, int G);
 
 // LayerNorm over rows of [M, C]; optional pre-add of a per-frame broadcast vector

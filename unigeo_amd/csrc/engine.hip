@@ -204,9 +204,14 @@ struct Epi {
 // GroupNorm statistics handed from the producing GEMM's epilogue to the GroupNorm that follows (GemmP::stat_part): allocated by the caller next to the
 // tensor, filled by conv() / linear() when the chosen kernel can (rb = rows per block, 0 = not written: groupnorm() then runs its statistics pass)
 struct StatPart { float2* part = nullptr; int rb = 0; };
-static StatPart stat_alloc(Ctx& c, long M, int N) {
+static StatPart stat_alloc(Ctx& c, long M, int N, int T, int hw, int G, int temporal) {
   StatPart s;
-  if (!(c.tune.knobs & 131072) && M >= 8192) s.part = (float2*)c.ws.get<float>(((M + 47) / 48) * (long)N * 2);   // 48 = the smallest wave tile; M >= 8192: below that GroupNorm keeps its one- / two-launch slab forms (4096 measured: +2 ms per clip)
+  // M >= 8192: below that GroupNorm keeps its one- / two-launch slab forms (4096 measured: +2 ms per clip); and only where launch_groupnorm would actually
+  // consume the partial sums for the (T, hw, N, G, temporal) GroupNorm that follows - the launcher's own rule (groupnorm_uses_part)
+  GroupNormP g; memset(&g, 0, sizeof(g));
+  g.C0 = N; g.T = T; g.HW = hw; g.G = G; g.temporal = temporal; g.gamma = c.zero; g.beta = c.zero;
+  if (!(c.tune.knobs & 131072) && M >= 8192 && N % G == 0 && groupnorm_uses_part(g, 16))
+    s.part = (float2*)c.ws.get<float>(((M + 47) / 48) * (long)N * 2);   // 48 = the smallest wave tile
   return s;
 }
 
@@ -873,7 +878,7 @@ static void res2d_forward(Ctx& c, const Res2D& r, const f16* x0, int C0, const f
   f16* a = c.ws.get<f16>(M * cin);
   groupnorm(c, x0, C0, x1, C1, T, h * w, G, r.n1, 0, 1, a, C1 == 0 ? in_stats : nullptr);
   f16* hb = c.ws.get<f16>(M * cout);
-  StatPart sh = stat_alloc(c, M, cout);      // the statistics of the second GroupNorm come out of the first convolution's epilogue
+  StatPart sh = stat_alloc(c, M, cout, T, h * w, G, 0);      // the statistics of the second GroupNorm come out of the first convolution's epilogue
   { Epi e; e.bias2 = tproj; e.so = &sh; conv(c, a, cin, nullptr, 0, T, h, w, r.c1, 1, 1, 1, 1, hb, e); }
   f16* b = c.ws.get<f16>(M * cout);
   groupnorm(c, hb, cout, nullptr, 0, T, h * w, G, r.n2, 0, 1, b, &sh);
@@ -896,10 +901,10 @@ static f16* stres_forward(Ctx& c, const STRes& rb, const f16* x0, int C0, const 
   const long M = (long)T * h * w;
   const int cout = rb.cout;
   f16* out = c.ws.get<f16>(M * cout);
-  if (out_stats) *out_stats = stat_alloc(c, M, cout);
+  if (out_stats) *out_stats = stat_alloc(c, M, cout, T, h * w, G, 0);
   const size_t mk = c.ws.mark();
   f16* xs = c.ws.get<f16>(M * cout);
-  StatPart sx = stat_alloc(c, M, cout), sh = stat_alloc(c, M, cout);
+  StatPart sx = stat_alloc(c, M, cout, T, h * w, G, 1), sh = stat_alloc(c, M, cout, T, h * w, G, 1);
   res2d_forward(c, rb.s, x0, C0, x1, C1, T, h, w, G, tproj_s, xs, &sx, in_stats);
   f16* a = c.ws.get<f16>(M * cout);
   groupnorm(c, xs, cout, nullptr, 0, T, h * w, G, rb.t.n1, 1, 1, a, &sx);

@@ -56,8 +56,8 @@ __global__ __launch_bounds__(12 * 64, 3) void conv_halo_kernel(const GemmP p) {
   const int txn = p.Wo >> LG, tpf = (p.Ho / TH) * txn;     // tiles per image row / per frame
 
   const int nwg = gridDim.x, w = blockIdx.x;
-  const int wslot = (nwg % 8 == 0 && !(p.flags & UG_F_NOXCD)) ? (w % 8) * (nwg / 8) + w / 8 : w;
-  const int my_tiles = (ntiles - wslot + nwg - 1) / nwg;
+  const TileWalk tw = tile_walk(p.flags, ntiles, nwg, w);    // XCD-owned runs of the walk order (kernels/gemm_common.h)
+  const int my_tiles = tw.count;
   const int total_it = my_tiles * nk;
 
   // tile -> frame / first output pixel (y0, x0) / first output column
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(12 * 64, 3) void conv_halo_kernel(const GemmP p) {
     // weights of one K step (+ the halo slices that ride with it); returns the number of halo loads issued
     auto issue = [&]() -> int {
       if (ld_ks == 0) {
-        int t, y0, x0, n0; tile_origin(wslot + ld_ti * nwg, t, y0, x0, n0);
+        int t, y0, x0, n0; tile_origin(tw.first + ld_ti * tw.step, t, y0, x0, n0);
 #pragma unroll
         for (int l = 0; l < LB; ++l) {
           const int rg = pw * LB + l;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(12 * 64, 3) void conv_halo_kernel(const GemmP p) {
         int tchunk = chunk + 1, ttile = ld_ti;
         if (tchunk == nchunks) { tchunk = 0; ++ttile; }
         if (ttile < my_tiles) {
-          if (ttile != h_tile) { halo_setup(wslot + ttile * nwg); h_tile = ttile; }
+          if (ttile != h_tile) { halo_setup(tw.first + ttile * tw.step); h_tile = ttile; }
 #pragma unroll
           for (int u = 0; u < HL; ++u) {
             const int k = (sp - 2) * HL + u;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(12 * 64, 3) void conv_halo_kernel(const GemmP p) {
     };
     // prologue: the whole halo of the first chunk, then steps 0 and 1; step 0 (and the halo, older) must have landed before the first barrier
     if (total_it > 0) {
-      halo_setup(wslot); h_tile = 0;
+      halo_setup(tw.first); h_tile = 0;
 #pragma unroll
       for (int k = 0; k < ngw_max; ++k) if (k < ngw) halo_issue(k, 0, 0);
       issue();
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(12 * 64, 3) void conv_halo_kernel(const GemmP p) {
       __builtin_amdgcn_sched_group_barrier(0x008, Q, 0);
     }
     if (tap == 8 && last_chunk) {
-      int t, y0, x0, n0; tile_origin(wslot + ti * nwg, t, y0, x0, n0);
+      int t, y0, x0, n0; tile_origin(tw.first + ti * tw.step, t, y0, x0, n0);
       const int m0 = (t * p.Ho + y0) * p.Wo + x0 - p.m_off;
       if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, (t * tpf + (y0 / TH) * txn + (x0 >> LG)) * (BM / WTM) + wm);
       else tile_epilogue<MT, NT, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, 0);

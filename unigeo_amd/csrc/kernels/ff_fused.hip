@@ -387,6 +387,8 @@ static void launch_ff_t(const FFusedP& p, hipStream_t s) {
       return;
     }
   }
+#else
+  UG_REQUIRE(variant < 100, "ff_fused: the ablation variants (100 + mask) exist only in the UG_EXPERIMENTS build (make experiments -> build/exp/libunigeo_exp.so, UG_LIB_PATH)");
 #endif
   if (variant == 0) {
     if constexpr (KT >= 2 && (KT * 64 + 127) / 128 >= 2) {

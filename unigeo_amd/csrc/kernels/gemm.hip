@@ -103,12 +103,12 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
   }
   const int nk = max(kt_hi - kt_lo, 1);   // an empty split still walks one (all-zero-source) step
 
-  // Persistent tile walk.  Workgroup w (observed to run on XCD w % 8) takes, in round i, tile
-  // i*nwg + (w%8)*(nwg/8) + w/8: the workgroups of one XCD work on a contiguous run of tiles (same A rows,
-  // neighbouring W panels) at the same time, so their operand panels hit in that XCD's L2.
+  // Persistent tile walk.  Workgroup w (observed to run on XCD w % 8) walks the contiguous run of tiles its XCD owns (tile_walk):
+  // the workgroups of one XCD work on neighbouring tiles (same A rows, neighbouring W panels) at the same time and from one
+  // round to the next, so their operand panels hit in that XCD's L2.
   const int nwg = gridDim.x, w = blockIdx.x;
-  const int wslot = (nwg % 8 == 0 && !(p.flags & UG_F_NOXCD)) ? (w % 8) * (nwg / 8) + w / 8 : w;
-  const int my_tiles = (ntiles - wslot + nwg - 1) / nwg;     // tiles wslot, wslot+nwg, ...
+  const TileWalk tw = tile_walk(p.flags, ntiles, nwg, w);    // tiles tw.first, tw.first + tw.step, ... (XCD-owned runs: kernels/gemm_common.h)
+  const int my_tiles = tw.count;
   const int total_it = my_tiles * nk;
 
   // ---- loader state for the tile currently being fetched ----
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
   };
   // fetch the next flat iteration (tile ld_ti of this workgroup, K-step ld_ks) into ring slot ld_slot
   auto issue = [&]() {
-    if (ld_ks == 0) setup_tile(wslot + ld_ti * nwg);
+    if (ld_ks == 0) setup_tile(tw.first + ld_ti * tw.step);
     stage((kt_lo + ld_ks) * BK, ld_slot);
     if (++ld_ks == nk) { ld_ks = 0; ++ld_ti; }
     if (++ld_slot == NST) ld_slot = 0;
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
 
     // ---- tile finished: epilogue (the next tile's operands keep streaming into the ring meanwhile) ----
     drain = true;
-    const int tile = wslot + ti * nwg;
+    const int tile = tw.first + ti * tw.step;
     { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn);
       if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm); else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
   }
@@ -459,8 +459,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ldr_kernel(const GemmP p) {
   const int nk = max(kt_hi - kt_lo, 1);
 
   const int nwg = gridDim.x, w = blockIdx.x;
-  const int wslot = (nwg % 8 == 0 && !(p.flags & UG_F_NOXCD)) ? (w % 8) * (nwg / 8) + w / 8 : w;
-  const int my_tiles = (ntiles - wslot + nwg - 1) / nwg;
+  const TileWalk tw = tile_walk(p.flags, ntiles, nwg, w);    // tiles tw.first, tw.first + tw.step, ... (XCD-owned runs: kernels/gemm_common.h)
+  const int my_tiles = tw.count;
   const int total_it = my_tiles * nk;
 
   // ---- loader state (waves 4-7): load l < AI belongs to the partner wave - 4, l >= AI to the wave itself ----
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ldr_kernel(const GemmP p) {
   int u_it = 0, u_iy = 0, u_ix = 0, u_cb = 0;
   auto issue = [&]() {
     if (ld_ks == 0) {
-      setup_tile(wslot + ld_ti * nwg);
+      setup_tile(tw.first + ld_ti * tw.step);
       if (CONV) {
         const int kt0 = kt_lo * BK;
         // chunk-major K: step q = kt0 / BK is (channel chunk q / taps, tap q % taps)
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ldr_kernel(const GemmP p) {
 #endif
     if (++cp_ks != nk) continue;
     cp_ks = 0;
-    const int tile = wslot + (cp_ti++) * nwg;
+    const int tile = tw.first + (cp_ti++) * tw.step;
     drain = true;
     { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn);
       if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm); else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
@@ -709,8 +709,8 @@ __global__ __launch_bounds__((WMW * WNW + 4) * 64, 3) void gemm_ws_kernel(const 
   const int nk = max(kt_hi - kt_lo, 1);
 
   const int nwg = gridDim.x, w = blockIdx.x;
-  const int wslot = (nwg % 8 == 0 && !(p.flags & UG_F_NOXCD)) ? (w % 8) * (nwg / 8) + w / 8 : w;
-  const int my_tiles = (ntiles - wslot + nwg - 1) / nwg;
+  const TileWalk tw = tile_walk(p.flags, ntiles, nwg, w);    // tiles tw.first, tw.first + tw.step, ... (XCD-owned runs: kernels/gemm_common.h)
+  const int my_tiles = tw.count;
   const int total_it = my_tiles * nk;
 
   if (producer) {
@@ -730,7 +730,7 @@ __global__ __launch_bounds__((WMW * WNW + 4) * 64, 3) void gemm_ws_kernel(const 
     int u_it = 0, u_iy = 0, u_ix = 0, u_cb = 0;
     auto issue = [&]() {
       if (ld_ks == 0) {
-        const int tile = wslot + ld_ti * nwg;
+        const int tile = tw.first + ld_ti * tw.step;
         int tm, tn; tile_coord_p(p, tile, ntm, ntn, tm, tn);
         const int m0 = tm * BM, n0 = tn * BN;
 #pragma unroll
@@ -891,7 +891,7 @@ __global__ __launch_bounds__((WMW * WNW + 4) * 64, 3) void gemm_ws_kernel(const 
     UG_STAMP(1);
     if (++cp_ks == nk) {
       cp_ks = 0;
-      const int tile = wslot + (cp_ti++) * nwg;
+      const int tile = tw.first + (cp_ti++) * tw.step;
       { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn); if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm); else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all fragment reads of this slot are done before it is handed back
@@ -1145,6 +1145,7 @@ void launch_gemm_mx8(const GemmP& p0, hipStream_t s) {
   p.K /= 2; p.C0 /= 2; p.ldw /= 2;          // bytes -> the loaders' fp16 units (see gemm_kernel<MX>)
   p.splitk = 1; p.cfg_p1 = 0;
   if (p.tune_knobs & 2) p.flags |= UG_F_NOXCD;
+  if (p.tune_knobs & 128) p.flags |= UG_F_XCDROUND;
   const int force = (p.tune_cfg_p1 - 1);
   // largest tile that still gives the 256 CUs ~one workgroup each (profiles/r02_mx8_per_shape.txt: 4800x1280x5120 on 256x256 tiles = 95
   // workgroups ran below the fp16 kernel)
@@ -1332,6 +1333,9 @@ static int pick_group_m(const GemmP& p, int cfg, int batch, int split) {
   const double P = 32.0 * percu;
   int g = 1;
   while (g * 2 <= ntm && (double)(g * 2) * (g * 2) <= P * bn / bm * 1.5) g *= 2;   // nearest power of two to sqrt(P bn / bm)
+  // round 5: a group of g x ntn tiles that fits the XCD's window of P tiles covers whole tile rows anyway - the row-major walk touches the same panels and a
+  // run boundary then splits ONE M tile's activation panel between two L2s instead of g (19200 x 640 x 2560, 5 column tiles: g = 4 -> 1).  Knob 1048576 = off.
+  if (!(p.tune_knobs & 1048576) && (double)g * ntn <= P) g = 1;
   return g;
 }
 
@@ -1340,6 +1344,7 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s, int* stat_rb) {
   if (stat_rb) *stat_rb = 0;
   if (!stat_rb) p.stat_part = nullptr;
   if (p.tune_knobs & 2) p.flags |= UG_F_NOXCD;
+  if (p.tune_knobs & 128) p.flags |= UG_F_XCDROUND;
   if (p.tune_knobs & 16) p.flags |= UG_F_PRIO;
   UG_REQUIRE(p.K % 8 == 0, "GEMM K must be a multiple of 8");
   UG_REQUIRE(p.ldw % 8 == 0, "GEMM ldw must be a multiple of 8");
@@ -1377,7 +1382,7 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s, int* stat_rb) {
       GemmP a = p; a.M = M1; a.cfg_p1 = 61;                     // config 60 (+ 1)
       a.stat_part = nullptr;                                      // (two tile geometries for one tensor: no epilogue statistics)
       GemmP b = p0; b.stat_part = nullptr; b.M = p.M - M1; b.m_off = M1; b.Out = (void*)((f16*)p.Out + (long)M1 * p.ldo);
-      if (p.flags & UG_F_NOXCD) b.flags |= UG_F_NOXCD;
+      b.flags |= p.flags & (UG_F_NOXCD | UG_F_XCDROUND);
       if (b.R1) b.R1 += (long)M1 * p.ldr1;
       if (b.R2) b.R2 += (long)M1 * p.ldr2;
       int cb, sb; gemm_plan(b, 1, &cb, &sb);

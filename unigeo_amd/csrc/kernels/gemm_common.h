@@ -66,6 +66,26 @@ __device__ __forceinline__ void tile_coord_p(const GemmP& p, int tile, int ntm, 
   if (p.tm_T) { const int q = tm / p.tm_T; tm = (tm - q * p.tm_T) * p.tm_nb + q; }
 }
 
+// Persistent tile walk of workgroup w of nwg (workgroup w is dispatched to XCD w % 8; each XCD has its own 4 MiB L2).
+//   owned (default since round 5): XCD x owns the CONTIGUOUS run [x * ntiles / 8, (x + 1) * ntiles / 8) of the walk order for the whole launch and its nwg / 8
+//     workgroups step through it nwg / 8 tiles at a time - every round of an XCD continues where its previous round stopped, so an operand panel (the A rows of
+//     an M tile with its N tiles, a group of tile_coord) is pulled into exactly one L2, except for the seven panels that straddle two XCDs' runs;
+//   round-strided (rounds 1 - 4, UG_F_XCDROUND / knob 128): round i of the launch is the run [i * nwg, (i + 1) * nwg) cut into eight pieces - the XCD's second
+//     round starts nwg tiles further on, and every round boundary x every XCD boundary can split a panel between two L2s (19200 x 640 x 2560 on 192 x 128 tiles,
+//     groups of 4 x 5: 15 of the 25 groups were read by two XCDs);
+//   no remap (UG_F_NOXCD / knob 2, or a grid that is not a multiple of 8): tile w + i * nwg.
+// The number of rounds is the same for all three: ceil(ceil(ntiles / 8) / (nwg / 8)) == ceil(ntiles / nwg) when nwg % 8 == 0.
+struct TileWalk { int first, step, count; };
+__device__ __forceinline__ TileWalk tile_walk(int flags, int ntiles, int nwg, int w) {
+  TileWalk t;
+  if (nwg % 8 != 0 || (flags & UG_F_NOXCD)) { t.first = w; t.step = nwg; t.count = (ntiles - w + nwg - 1) / nwg; return t; }
+  const int x = w & 7, j = w >> 3, npx = nwg >> 3;
+  if (flags & UG_F_XCDROUND) { t.first = x * npx + j; t.step = nwg; t.count = (ntiles - t.first + nwg - 1) / nwg; return t; }
+  const int lo = (int)(((long)x * ntiles) >> 3), hi = (int)(((long)(x + 1) * ntiles) >> 3);
+  t.first = lo + j; t.step = npx; t.count = max(0, (hi - lo - j + npx - 1) / npx);
+  return t;
+}
+
 template <int N> struct HVec;
 template <> struct HVec<8> { typedef f16x8 type; };
 template <> struct HVec<4> { typedef f16x4 type; };
@@ -237,6 +257,7 @@ template <int MT, int NT, int WTM, int WTN>
 __device__ __forceinline__ void tile_epilogue_stats(const GemmP& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wm, int wn, int lane, int stat_blk) {
   constexpr int WID = 4 * NT;
   static_assert(WID % 8 == 0, "statistics epilogue: 8-column chunks");
+  static_assert(WID <= 16, "statistics epilogue: a lane's WID-column run is stored whole or not at all - launch_gemm only guarantees N % 16 == 0");
   const int l15 = lane & 15, g = lane >> 4;
   const int nb = n0 + wn * WTN + g * WID;
   const bool full = (nb + WID <= p.N);

@@ -523,11 +523,9 @@ size_t groupnorm_ws_floats(int T, int HW, int C, int G) {
 // Also measured and removed: apply with an in-block finalize (2 launches; +3.5 us of serial latency per workgroup, no
 // gain) and a single launch with a device-scope barrier (agent-scope release/acquire flushes and invalidates the whole
 // L2: 162 ms of GroupNorm per clip; with the partials as coherent atomics instead: 140 ms; three launches: 113 ms).
-void launch_groupnorm(const GroupNormP& p, hipStream_t s) {
+// launch scheme launch_groupnorm takes for p (p.mode == 0: the measured rules below); *svmax_o / *tvmax_o / *snt_o / *tnt_o = the slab plans
+static int gn_pick_mode(const GroupNormP& p, int* snt_o = nullptr, int* svmax_o = nullptr, int* tnt_o = nullptr, int* tvmax_o = nullptr) {
   const int C = p.C0 + p.C1;
-  UG_REQUIRE(p.C0 % 8 == 0 && p.C1 % 8 == 0, "GroupNorm channels must be multiples of 8");
-  UG_REQUIRE(C % p.G == 0 && p.G <= 256 && 256 % p.G == 0, "GroupNorm group count must divide 256");
-  UG_REQUIRE(C <= GN_MAXV * GN_THREADS * 8, "GroupNorm too many channels");
   const int cpg = C / p.G;
   const long slab = (long)p.HW * cpg * (p.temporal ? p.T : 1);
   const bool small_ok = !p.temporal && cpg % 4 == 0 && p.C0 % 4 == 0 && p.gamma && p.beta;
@@ -552,6 +550,29 @@ void launch_groupnorm(const GroupNormP& p, hipStream_t s) {
   if (mode == 2 && !small_ok) mode = 1;
   if (mode == 3) mode = 1;   // (3 was round 3's one-launch ticket scheme: slower than three launches everywhere, removed in round 4)
   if (mode == 6 && !tnt) mode = 1;
+  if (snt_o) *snt_o = snt;
+  if (svmax_o) *svmax_o = svmax;
+  if (tnt_o) *tnt_o = tnt;
+  if (tvmax_o) *tvmax_o = tvmax;
+  return mode;
+}
+// true when launch_groupnorm would take the statistics from GroupNormP::part (the producing GEMM's epilogue) for this tensor - the same rule the launcher
+// applies, so that a caller (engine.hip: stat_alloc, the op test) never makes a producer write partial sums that the slab / small forms then ignore
+bool groupnorm_uses_part(const GroupNormP& p0, int part_rb) {
+  GroupNormP p = p0;
+  if ((p.C0 + p.C1) % p.G != 0 || p.C1 != 0 || p.mode != 0 || part_rb <= 0 || p.HW % part_rb != 0) return false;
+  const int mode = gn_pick_mode(p);
+  return mode == 1 || mode == 6;
+}
+
+bool launch_groupnorm(const GroupNormP& p, hipStream_t s) {
+  const int C = p.C0 + p.C1;
+  UG_REQUIRE(p.C0 % 8 == 0 && p.C1 % 8 == 0, "GroupNorm channels must be multiples of 8");
+  UG_REQUIRE(C % p.G == 0 && p.G <= 256 && 256 % p.G == 0, "GroupNorm group count must divide 256");
+  UG_REQUIRE(C <= GN_MAXV * GN_THREADS * 8, "GroupNorm too many channels");
+  const int cpg = C / p.G;
+  int snt = 0, svmax = 0, tnt = 0, tvmax = 0;
+  int mode = gn_pick_mode(p, &snt, &svmax, &tnt, &tvmax);
   if (p.part && p.mode == 0 && (mode == 1 || mode == 6)) {
     // the producing GEMM's epilogue left per-block column sums (GemmP::stat_part): no statistics pass over X - combine them, apply
     UG_REQUIRE(p.C1 == 0 && p.part_rb > 0 && p.HW % p.part_rb == 0, "GroupNorm: epilogue statistics need a single source and whole blocks per frame");
@@ -569,7 +590,7 @@ void launch_groupnorm(const GroupNormP& p, hipStream_t s) {
     }
     hipLaunchKernelGGL(gn_apply, dim3(nchunk, p.T), dim3(GN_THREADS), 0, s, p, rpc, (const float*)ab);
     UG_CHECK(hipGetLastError());
-    return;
+    return true;
   }
   if (mode == 4) {
     gn_slab_launch<0>(p, snt, svmax, dim3(p.G, p.temporal ? 1 : p.T), s);
@@ -590,6 +611,7 @@ void launch_groupnorm(const GroupNormP& p, hipStream_t s) {
     hipLaunchKernelGGL(gn_apply, dim3(nchunk, p.T), dim3(GN_THREADS), 0, s, p, rpc, (const float*)ab);
   }
   UG_CHECK(hipGetLastError());
+  return false;
 }
 
 // ------------------------------------------------------------------------------------------
