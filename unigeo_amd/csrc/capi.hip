@@ -130,6 +130,11 @@ int ug_set_ff_fused(ug_ctx* x, int on) {
   x->c.ff_fused = on & 3; x->c.lane_need.clear();   // bit 0: fused feed-forward kernel, bit 1: its pre-LayerNorm inside the kernel  (a feature toggle changes the transient memory a lane task needs) LayerNorm -> Q|K|V projection
   return 0;
 }
+int ug_set_ln_fold(ug_ctx* x, int mode) {
+  if (!x) return -1;
+  x->c.ln_fold = mode < 0 ? 0 : (mode > 2 ? 2 : mode); x->c.lane_need.clear();
+  return 0;
+}
 int ug_set_fp8_linears(ug_ctx* x, int on) {
   if (!x) return -1;
   x->c.fp8_linears = on ? 1 : 0; x->c.lane_need.clear();
@@ -795,6 +800,89 @@ int ug_op_layernorm(ug_ctx* x, const float* xin, int M, int C, float eps, const 
     launch_layernorm(p, c.stream);
     down16(c, y, out, (long)M * C);
     if (xo && xout) down16(c, xo, xout, (long)M * C);
+  });
+}
+
+// Projection -> LayerNorm -> linear, the round-5 folded forms against the three-pass form (tests/test_ops_gpu.py::test_layernorm_folded_into_consumer_gemm):
+//   s = A Wp^T + bp (+ R) (+ vec[row / rows_per_vec]),  y = (GEGLU of) LayerNorm(s) W^T + bias
+// mode 0: projection, LayerNorm launch (adds vec, writes s), GEMM - rounds 1 - 4;  mode 1: projection, statistics-only LayerNorm launch (adds vec, writes s),
+// GEMM on the raw s with the normalisation in its epilogue;  mode 2: the projection adds vec itself (per-row-block bias2) and leaves row partial sums,
+// k_rowstat_finalize, folded GEMM.  slots_out = row-partial slots the projection wrote (mode 2; 0 = it declined and the statistics launch ran instead).
+int ug_op_proj_ln_linear(ug_ctx* x, const float* A, int M, int K0, const float* Wp, const float* bp, int C, const float* R, const float* vec, int rows_per_vec,
+                         const float* gamma, const float* beta, float eps, const float* W, const float* bias, int N, int geglu, int mode,
+                         float* s_out, float* y_out, int* slots_out) {
+  UG_TRY(x, {
+    Ctx& c = x->c; Scope sc(c);
+    std::vector<float> Wq, bq;
+    const float* Wu = W; const float* bu = bias;
+    if (geglu) {   // same row interleave as bind_geglu
+      const int inner = N / 2;
+      Wq.resize((size_t)N * C); if (bias) bq.resize(N);
+      for (int v = 0; v < N; ++v) {
+        const int blk = v / 16, wv = v % 16;
+        const int src = wv < 8 ? blk * 8 + wv : inner + blk * 8 + (wv - 8);
+        memcpy(&Wq[(size_t)v * C], &W[(size_t)src * C], (size_t)C * 4);
+        if (bias) bq[v] = bias[src];
+      }
+      Wu = Wq.data(); if (bias) bu = bq.data();
+    }
+    const int Nout = geglu ? N / 2 : N;
+    f16* dA = up16(c, A, (long)M * K0); f16* dWp = up16(c, Wp, (long)C * K0); f16* dbp = up16_opt(c, bp, C);
+    f16* dR = up16_opt(c, R, (long)M * C);
+    const int nv = vec ? (M + rows_per_vec - 1) / rows_per_vec : 0;
+    f16* dvec = up16_opt(c, vec, (long)nv * C);
+    f16* dg = up16(c, gamma, C); f16* dbeta = up16(c, beta, C);
+    f16* dW = up16(c, Wu, (long)N * C); f16* db = up16_opt(c, bu, N);
+    f16* s0 = c.ws.get<f16>((long)M * C); f16* s1 = c.ws.get<f16>((long)M * C); f16* t1 = c.ws.get<f16>((long)M * C);
+    f16* dY = c.ws.get<f16>((long)M * Nout);
+    float2* stat = (float2*)c.ws.get<float>((long)M * 2);
+    const int cap = 40;
+    float2* part = (float2*)c.ws.get<float>((long)M * cap * 2);
+    f16* wf = c.ws.get<f16>((long)N * C); float* fs = c.ws.get<float>(N); float* fb = c.ws.get<float>(N);
+    auto plan = [&](GemmP& p) { gemm_apply_tune(p, c.tune); int cf, sp; gemm_plan(p, 1, &cf, &sp); p.cfg_p1 = cf + 1; p.splitk = sp; if (sp > 1) p.partial = c.ws.get<float>((long)sp * p.M * p.N); };
+    GemmP pp; memset(&pp, 0, sizeof(pp));
+    pp.A0 = dA; pp.C0 = K0; pp.M = M; pp.N = C; pp.K = K0; pp.W = dWp; pp.ldw = K0; pp.bias = dbp; pp.R1 = dR; pp.ldr1 = C; pp.c0 = 1.f; pp.c1 = 1.f;
+    pp.ldo = C; pp.zero = c.zero; pp.nb_inner = 1;
+    GemmP pc; memset(&pc, 0, sizeof(pc));
+    pc.C0 = C; pc.M = M; pc.N = N; pc.K = C; pc.ldw = C; pc.c0 = 1.f; pc.flags = geglu ? UG_F_GEGLU : 0; pc.Out = dY; pc.ldo = Nout; pc.zero = c.zero; pc.nb_inner = 1;
+    int slots = 0;
+    const f16* s_final = s0;
+    if (mode == 0) {
+      pp.Out = s0; plan(pp); launch_gemm(pp, 1, c.stream);
+      LayerNormP l; memset(&l, 0, sizeof(l));
+      l.X = s0; l.Y = t1; l.M = M; l.C = C; l.eps = eps; l.gamma = dg; l.beta = dbeta;
+      if (dvec) { l.addvec = dvec; l.rows_per_vec = rows_per_vec; l.Xout = s1; s_final = s1; }
+      launch_layernorm(l, c.stream);
+      pc.A0 = t1; pc.W = dW; pc.bias = db; plan(pc); launch_gemm(pc, 1, c.stream);
+    } else {
+      launch_fold_ln_weights(dW, db, dg, dbeta, wf, fs, fb, N, C, c.stream);
+      bool have = false;
+      if (mode == 2) {
+        GemmP q = pp; q.Out = s1; q.want_ext = 1; plan(q);
+        int want = 0;
+        if (gemm_epilogue_ext_ok(q, 1, &want) && want <= cap) {
+          q.row_part = part;
+          if (dvec) { q.bias2 = dvec; q.bias2_rows = rows_per_vec >= M ? 0 : rows_per_vec; }
+          launch_gemm(q, 1, c.stream, nullptr, &slots);
+          s_final = s1; have = true;
+          if (slots > 0) launch_rowstat_finalize(part, slots, M, C, eps, stat, c.stream);
+          else { LayerNormP l; memset(&l, 0, sizeof(l)); l.X = s1; l.M = M; l.C = C; l.eps = eps; l.gamma = dg; l.beta = dbeta; l.stat_out = stat; launch_layernorm(l, c.stream); }
+        }
+      }
+      if (!have) {
+        pp.Out = s0; plan(pp); launch_gemm(pp, 1, c.stream);
+        LayerNormP l; memset(&l, 0, sizeof(l));
+        l.X = s0; l.M = M; l.C = C; l.eps = eps; l.gamma = dg; l.beta = dbeta; l.stat_out = stat;
+        if (dvec) { l.addvec = dvec; l.rows_per_vec = rows_per_vec; l.Xout = s1; s_final = s1; }
+        launch_layernorm(l, c.stream);
+      }
+      pc.A0 = s_final; pc.W = wf; pc.ln_stat = stat; pc.ln_s = fs; pc.ln_bias = fb; pc.want_ext = 1; plan(pc);
+      UG_REQUIRE(gemm_epilogue_ext_ok(pc, 1), "ug_op_proj_ln_linear: the consumer's tile cannot take the LayerNorm fold");
+      launch_gemm(pc, 1, c.stream);
+    }
+    if (slots_out) *slots_out = slots;
+    if (s_out) down16(c, s_final, s_out, (long)M * C);
+    down16(c, dY, y_out, (long)M * Nout);
   });
 }
 

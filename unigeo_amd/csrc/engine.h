@@ -35,6 +35,8 @@ class Arena {
 };
 
 struct Lin { const f16* w = nullptr; const f16* b = nullptr; int in = 0, out = 0;
+             // LayerNorm folded in (round 5, fold_ln at bind time): wf = fp16(gamma o w), fs[n] = sum_k wf[n][k], fb[n] = b[n] + sum_k beta[k] w[n][k] (GemmP::ln_stat)
+             const f16* wf = nullptr; const float* fs = nullptr; const float* fb = nullptr;
              // optional MX-fp8 copy of the weight (kernels/mx8.hip): e4m3 bytes [out][in] + e8m0 block scales [in/128][ld_sw8] dwords
              const unsigned char* w8 = nullptr; const unsigned* sw8 = nullptr; long ld_sw8 = 0; };
 struct Conv { const f16* w = nullptr; const f16* b = nullptr; int cin = 0, cinp = 0, cout = 0, kt = 1, ky = 1, kx = 1;
@@ -168,6 +170,7 @@ struct Ctx {
                              // register file of every CU, so a second stream's kernels only get the tail rounds
   std::map<std::string, size_t> lane_need;
   int cur_lane = 0;          // 0 = main stream, l + 1 = lane l (run_lanes)
+  int ln_fold = 1;           // LayerNorm folded into its consumer GEMM (engine.hip: transformer_forward): 0 off, 1 where it pays (M >= 4096), 2 wherever the kernels can (tests)
   int ff_variant = 0, flash_variant = -1;   // ug_tune_ff / ug_tune_flash: per-context A/B overrides copied into FFusedP / FlashP (0 / -1 = the defaults)
   GemmTune tune;             // ug_tune_force: tile-config / split-K / knob overrides for THIS context's GEMM launches (tests, A/B tools)
 };

@@ -56,7 +56,7 @@ template <int BM, int BN, int BK, int NST, int WMW, int WNW> struct GemmOcc {
 // loaders are byte movers, so an fp8 [rows][K] matrix is staged exactly like an fp16 [rows][K/2] one (the launcher halves K / lda /
 // ldw): a 128-byte LDS row is one 128-deep K step.  The block scales of a K step (one dword = 4 e8m0 per row) ride the same ring:
 // wave 0 / wave 1 fetch the A / W scale dwords of the tile's rows with one extra 1 KiB direct-to-LDS load each.
-template <int BM, int BN, int BK, int NST, int WMW, int WNW, bool CONV, bool UNI, bool BUFA = false, bool MX = false, bool ST = false>   // ST: statistics epilogue (GemmP::stat_part)
+template <int BM, int BN, int BK, int NST, int WMW, int WNW, bool CONV, bool UNI, bool BUFA = false, bool MX = false, bool ST = false, bool EXT = false>   // ST: statistics epilogue (GemmP::stat_part); EXT: round-5 epilogue extensions (tile_epilogue)
 __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>::wps)) void gemm_kernel(const GemmP p) {
   static_assert(!BUFA || !CONV || UNI, "buffer addressing needs the single-tap K tiles");
   static_assert(!MX || (!CONV && BK == 64 && BM <= 256 && BN <= 256), "MX path: dense, 128-byte K steps, <= 256 scale rows per operand");
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
     drain = true;
     const int tile = tw.first + ti * tw.step;
     { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn);
-      if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm); else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
+      if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm); else tile_epilogue<MT, NT, WTM, WTN, EXT>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
   }
 }
 
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
 // their fragment reads and MFMAs, so the matrix pipe runs the partner's K-step while the loader is queued on the
 // address path, and the loader's K-step afterwards.  Same LDS image, ring, barrier and MFMA order as gemm_kernel
 // (outputs are bit-identical).
-template <int BM, int BN, int NST, int WMW, int WNW, bool CONV, bool ST = false>   // ST: statistics epilogue (GemmP::stat_part)
+template <int BM, int BN, int NST, int WMW, int WNW, bool CONV, bool ST = false, bool EXT = false>   // ST: statistics epilogue (GemmP::stat_part); EXT: round-5 epilogue extensions
 __global__ __launch_bounds__(512, 2) void gemm_ldr_kernel(const GemmP p) {
   constexpr int BK = 64;
   static_assert(WMW * WNW == 8, "two waves per SIMD");
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ldr_kernel(const GemmP p) {
     const int tile = tw.first + (cp_ti++) * tw.step;
     drain = true;
     { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn);
-      if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm); else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
+      if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm); else tile_epilogue<MT, NT, WTM, WTN, EXT>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
   }
 }
 
@@ -672,7 +672,7 @@ static bool gemm_can_bufa(const GemmP& p, int BK, bool packed) {
 // publishes step i+1 and frees slot i % 3.  Only producers ever have loads in flight in the K loop, so the epilogue's
 // global traffic (consumers) needs no drain logic.  LDS image, W row permutation, MFMA chain order and epilogue are those
 // of gemm_kernel: outputs are bit-identical.
-template <int BM, int BN, int WMW, int WNW, bool CONV, bool ST = false>   // ST: GroupNorm statistics of the output from the epilogue (GemmP::stat_part)
+template <int BM, int BN, int WMW, int WNW, bool CONV, bool ST = false, bool EXT = false>   // ST: GroupNorm statistics of the output from the epilogue (GemmP::stat_part); EXT: round-5 epilogue extensions
 __global__ __launch_bounds__((WMW * WNW + 4) * 64, 3) void gemm_ws_kernel(const GemmP p) {
   constexpr int NST = 3;
   constexpr int BK = 64;
@@ -892,7 +892,7 @@ __global__ __launch_bounds__((WMW * WNW + 4) * 64, 3) void gemm_ws_kernel(const 
     if (++cp_ks == nk) {
       cp_ks = 0;
       const int tile = tw.first + (cp_ti++) * tw.step;
-      { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn); if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm); else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
+      { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn); if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm); else tile_epilogue<MT, NT, WTM, WTN, EXT>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all fragment reads of this slot are done before it is handed back
     UG_STAMP(2);
@@ -907,6 +907,8 @@ __global__ __launch_bounds__((WMW * WNW + 4) * 64, 3) void gemm_ws_kernel(const 
 #endif
   }
 }
+
+static inline bool gemm_wants_ext(const GemmP& p) { return p.ln_stat || p.row_part || p.bias2_rows > 0; }
 
 template <int BN, int WMW, int WNW, int BM = 256>
 static void launch_ws(const GemmP& p, int batch, hipStream_t s) {
@@ -937,6 +939,16 @@ static void launch_ws(const GemmP& p, int batch, hipStream_t s) {
       hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, WMW, WNW, true, true>), grid, dim3((WMW * WNW + 4) * 64), lds, s, p);
       return;
     } else UG_REQUIRE(false, "producer / consumer kernel: epilogue statistics on 128-column tiles only");
+  }
+  if (gemm_wants_ext(p)) {   // launch_gemm (gemm_epilogue_ext_ok): dense launches on the 192 x 128 tiles only
+    if constexpr (BM == 192 && BN == 128) {
+      UG_REQUIRE(!p.conv, "producer / consumer kernel: the round-5 epilogue extensions are dense only");
+      static bool attre[32] = {};
+      bool& ate = attre[ug_dev_slot()];
+      if (!ate) { UG_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<BM, BN, WMW, WNW, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ate = true; }
+      hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, WMW, WNW, false, false, true>), grid, dim3((WMW * WNW + 4) * 64), lds, s, p);
+      return;
+    } else UG_REQUIRE(false, "producer / consumer kernel: epilogue extensions on the 192 x 128 tiles only");
   }
   if (p.conv) hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, WMW, WNW, true>), grid, dim3((WMW * WNW + 4) * 64), lds, s, p);
   else hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, WMW, WNW, false>), grid, dim3((WMW * WNW + 4) * 64), lds, s, p);
@@ -974,6 +986,7 @@ static void launch_ldr(const GemmP& p, int batch, hipStream_t s) {
       return;
     } else UG_REQUIRE(false, "loader kernel: epilogue statistics on the 256 x 256 tile only");
   }
+  UG_REQUIRE(!gemm_wants_ext(p), "loader kernel: no instantiation with the round-5 epilogue extensions (the 256 x 256 tile spills 476 bytes per lane with them)");
   if (p.conv) hipLaunchKernelGGL((gemm_ldr_kernel<BM, BN, NST, WMW, WNW, true>), grid, dim3(512), lds, s, p);
   else hipLaunchKernelGGL((gemm_ldr_kernel<BM, BN, NST, WMW, WNW, false>), grid, dim3(512), lds, s, p);
 }
@@ -1018,7 +1031,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue(const GemmP p) {
   }
 }
 
-template <int BM, int BN, int BK, int NST, int WMW, int WNW, bool CONV, bool UNI, bool BUFA = false, bool ST = false>
+template <int BM, int BN, int BK, int NST, int WMW, int WNW, bool CONV, bool UNI, bool BUFA = false, bool ST = false, bool EXT = false>
 static void launch_t(const GemmP& p, int batch, hipStream_t s) {
   const int ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
 #ifdef UG_GEMM_TRACE
@@ -1026,7 +1039,7 @@ static void launch_t(const GemmP& p, int batch, hipStream_t s) {
 #else
   const size_t lds = (size_t)NST * (BM + BN) * BK * sizeof(f16);
 #endif
-  auto kern = gemm_kernel<BM, BN, BK, NST, WMW, WNW, CONV, UNI, BUFA, false, ST>;
+  auto kern = gemm_kernel<BM, BN, BK, NST, WMW, WNW, CONV, UNI, BUFA, false, ST, EXT>;
   static bool attr[32] = {};
   bool& at = attr[ug_dev_slot()];
   if (!at) {
@@ -1066,6 +1079,10 @@ static void launch_mode(const GemmP& p, int batch, hipStream_t s) {
   } else {
     // dense: measured +4-6 % on the 8-wave tiles, -1..-4 % on the 4-wave 128x64 / 256x64 ones (profiles/r01_gemm_buffer_addressing.txt)
     const bool bufa = bufw && p.K % BK == 0 && (long)p.M * p.C0 * 2 < lim && (BM * BN >= 256 * 128 || (p.tune_knobs & 8));
+    if (gemm_wants_ext(p)) {   // launch_gemm (gemm_epilogue_ext_ok): of the symmetric kernel only the 3-stage 128 x 64 and the 128 x 128 tiles (configs 3 / 0: few-row launches), flat addressing
+      if constexpr ((BM == 128 && BN == 64 && NST == 3) || (BM == 128 && BN == 128 && NST == 2)) { launch_t<BM, BN, BK, NST, WMW, WNW, false, false, false, false, true>(p, batch, s); return; }
+      else UG_REQUIRE(false, "symmetric kernel: epilogue extensions on the 3-stage 128 x 64 and the 128 x 128 tiles only");
+    }
     if (bufa) launch_t<BM, BN, BK, NST, WMW, WNW, false, false, true>(p, batch, s);
     else launch_t<BM, BN, BK, NST, WMW, WNW, false, false>(p, batch, s);
   }
@@ -1306,6 +1323,9 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
   }
   // (a former rule - four K slices of the 128x128 tile for the 12x16 level's concatenated 2560-channel convs, 880 TFLOP/s - is gone:
   // the 192-row tile fills the chip there without split-K, 236 vs 324 us = 1200 TFLOP/s)
+  // a launch that is to carry the round-5 epilogue extensions (LayerNorm fold, row partial sums, per-row bias2) needs a kernel instantiated with them
+  // (gemm_epilogue_ext_ok): the 192 x 128 producer / consumer tiles stand in for the 256-row ones (19200 x 5120 x 640 GEGLU: 137 vs 129 us in situ)
+  if (p.want_ext && !p.conv && batch == 1 && split == 1 && cfg != 0 && cfg != 3 && cfg != 63 && cfg != 64 && gemm_can_bufa(p, 64, true) && p.M > 2048) cfg = (geglu || cfg == 54 || cfg == 62) ? 64 : 63;
   if ((p.tune_cfg_p1 - 1) >= 0 && !(geglu && (p.tune_cfg_p1 - 1) != 0 && (p.tune_cfg_p1 - 1) != 4 && (p.tune_cfg_p1 - 1) != 8 && (p.tune_cfg_p1 - 1) != 15 && (p.tune_cfg_p1 - 1) != 35 && (p.tune_cfg_p1 - 1) != 54 && (p.tune_cfg_p1 - 1) != 62 && (p.tune_cfg_p1 - 1) != 64)) cfg = (p.tune_cfg_p1 - 1);
   if ((p.tune_split_p1 - 1) >= 0) split = plain_epi ? std::max(1, (p.tune_split_p1 - 1)) : 1;
   *cfg_out = cfg; *split_out = split;
@@ -1339,10 +1359,52 @@ static int pick_group_m(const GemmP& p, int cfg, int batch, int split) {
   return g;
 }
 
-void launch_gemm(const GemmP& p0, int batch, hipStream_t s, int* stat_rb) {
+// Block / wave geometry of the tile configs whose epilogue is tile_epilogue (kernels/gemm_common.h) - ONE table for everything that depends on it: the
+// GroupNorm statistics blocks (wave tile rows), the row-partial slots (wave tile columns) and the LayerNorm-fold / per-row bias2 checks.  The fall-back
+// kernels of launch_cfg (no buffer addressing) have the geometry of the config they replace.  false: config 60 (20-column lane runs), the halo-staged and
+// the streaming kernels (their own epilogues).
+static bool cfg_geom(int cfg, int& bm, int& bn, int& wmw, int& wnw) {
+  switch (cfg) {
+    case 0: bm = 128; bn = 128; wmw = 2; wnw = 2; return true;
+    case 1: case 3: bm = 128; bn = 64; wmw = 2; wnw = 2; return true;
+    case 4: case 8: case 54: bm = 256; bn = 128; wmw = 4; wnw = 2; return true;
+    case 12: bm = 64; bn = 64; wmw = 2; wnw = 2; return true;
+    case 14: case 34: bm = 256; bn = 64; wmw = 4; wnw = 2; return true;
+    case 15: case 35: bm = 256; bn = 256; wmw = 2; wnw = 4; return true;
+    case 19: case 39: case 59: bm = 256; bn = 128; wmw = 2; wnw = 4; return true;
+    case 61: case 63: bm = 192; bn = 128; wmw = 2; wnw = 4; return true;
+    case 62: case 64: bm = 192; bn = 128; wmw = 4; wnw = 2; return true;
+    default: return false;
+  }
+}
+
+// Can THIS launch (the planner's tile for p, or the forced one) take the round-5 epilogue extensions - LayerNorm fold (GemmP::ln_stat), row partial sums
+// (GemmP::row_part), per-row-block bias2 (GemmP::bias2_rows)?  The engine asks before it commits a site to the folded form; launch_gemm requires it.
+// *slots = row_part slots the launch would write (column tiles x wave columns).
+bool gemm_epilogue_ext_ok(const GemmP& p0, int batch, int* slots) {
+  GemmP p = p0;
+  int cfg = p.cfg_p1 - 1, split = p.splitk;
+  if (cfg < 0 || split < 1) { int c2, s2; gemm_plan(p, batch, &c2, &s2); if (cfg < 0) cfg = c2; if (split < 1) split = s2; }
+  if (p.conv || batch != 1 || split != 1 || p.up_phase || (p.flags & UG_F_OUT_F32) || p.N % 64 != 0 || p.ldo % 8 != 0) return false;
+  if ((p.R1 && p.ldr1 % 8 != 0) || (p.R2 && p.ldr2 % 8 != 0)) return false;
+  if (!(p.tune_knobs & 65536) && (p.tune_cfg_p1 - 1) < 0 && gemm_stream_supported(p, batch)) return false;   // the streaming kernel takes it (its own epilogue)
+  int bm, bn, wmw, wnw;
+  if (!cfg_geom(cfg, bm, bn, wmw, wnw)) return false;
+  // the kernels instantiated with the extensions: the 3-stage 128 x 64 and the 128 x 128 symmetric tiles (3 / 0) and the dense 192 x 128 producer / consumer
+  // kernels (63 / 64; only in their buffer-addressed form - launch_cfg falls back to the symmetric kernel otherwise).  Not the 256 x 256 tiles: 128 accumulator
+  // registers per lane leave no room (476 bytes of scratch per lane measured) - GemmP::want_ext makes the planner pick 63 / 64 instead of them.
+  const bool pk = (cfg == 63 || cfg == 64) && gemm_can_bufa(p, 64, true);
+  if (!(cfg == 3 || cfg == 0 || pk)) return false;
+  if (slots) *slots = cdiv(p.N, bn) * wnw;
+  return true;
+}
+
+void launch_gemm(const GemmP& p0, int batch, hipStream_t s, int* stat_rb, int* row_slots) {
   GemmP p = p0;
   if (stat_rb) *stat_rb = 0;
   if (!stat_rb) p.stat_part = nullptr;
+  if (row_slots) *row_slots = 0;
+  if (!row_slots) p.row_part = nullptr;
   if (p.tune_knobs & 2) p.flags |= UG_F_NOXCD;
   if (p.tune_knobs & 128) p.flags |= UG_F_XCDROUND;
   if (p.tune_knobs & 16) p.flags |= UG_F_PRIO;
@@ -1436,17 +1498,14 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s, int* stat_rb) {
     // GroupNorm statistics of the output from the epilogue (GemmP::stat_part): one block per wave tile of WTM rows.  Only where every row of every tile
     // is stored through the epilogue's fp16 vector path and the blocks do not straddle frames; otherwise the caller runs the statistics pass.  Knob 131072 = off.
     int bm = 0, wmw = 0;
-    switch (cfg) {   // the kernels instantiated with the statistics epilogue: halo tiles of 128 columns, the producer / consumer tiles of 128 columns (convolutions)
-      case 71: bm = 256; wmw = 4; break;
-      case 72: bm = 192; wmw = 4; break;
-      case 14: if (p.conv && gemm_can_bufa(p, 64, false) && !(p.tune_knobs & 4)) { bm = 256; wmw = 4; } break;   // (the symmetric kernel: temporal convolutions onto <= 320 columns)
-      case 19: if (p.conv && gemm_can_bufa(p, 64, false) && !(p.tune_knobs & 4)) { bm = 256; wmw = 2; } break;   // (... and onto 128 columns at the VAE decoder's full resolution)
-      case 35: if (p.conv && gemm_can_bufa(p, 64, true)) { bm = 256; wmw = 2; } break;                             // loader kernel, 256 x 256 tile
-      case 54: if (p.conv && gemm_can_bufa(p, 64, true)) { bm = 256; wmw = 4; } break;
-      case 59: if (p.conv && gemm_can_bufa(p, 64, true)) { bm = 256; wmw = 2; } break;
-      case 63: if (p.conv && gemm_can_bufa(p, 64, true)) { bm = 192; wmw = 2; } break;
-      case 64: if (p.conv && gemm_can_bufa(p, 64, true)) { bm = 192; wmw = 4; } break;
-      default: break;
+    {   // the kernels instantiated with the statistics epilogue: halo tiles of 128 columns; of the tile_epilogue family (geometry: cfg_geom) the buffer-addressed
+        // im2col forms of 14 / 19 (symmetric kernel), 35 (loader kernel) and 54 / 59 / 63 / 64 (producer / consumer kernel)
+      int gbm, gbn, gwm, gwn;
+      const bool sym = (cfg == 14 || cfg == 19) && p.conv && gemm_can_bufa(p, 64, false) && !(p.tune_knobs & 4);
+      const bool pk = (cfg == 35 || cfg == 54 || cfg == 59 || cfg == 63 || cfg == 64) && p.conv && gemm_can_bufa(p, 64, true);
+      if (cfg == 71) { bm = 256; wmw = 4; }
+      else if (cfg == 72) { bm = 192; wmw = 4; }
+      else if ((sym || pk) && cfg_geom(cfg, gbm, gbn, gwm, gwn)) { bm = gbm; wmw = gwm; }
     }
     const int wtm = bm ? bm / wmw : 0;
     const bool ok = bm && split == 1 && batch == 1 && !(p.flags & (UG_F_GEGLU | UG_F_OUT_F32 | UG_F_R1_F32)) && !p.up_phase && !(p.tune_knobs & 131072) &&
@@ -1455,6 +1514,16 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s, int* stat_rb) {
     static const bool sdbg = getenv("UG_STAT_DEBUG") != nullptr;
     if (sdbg) fprintf(stderr, "[stat] M %d N %d K %d conv %d kt %d hw %d cfg %d split %d -> rb %d\n", p.M, p.N, p.K, p.conv, p.kt, p.stat_hw, cfg, split, ok ? wtm : 0);
     if (ok) *stat_rb = wtm; else p.stat_part = nullptr;
+  }
+  if (p.ln_stat || p.row_part || p.bias2_rows) {
+    int slots = 0;
+    GemmP q = p; q.cfg_p1 = cfg + 1; q.splitk = split;
+    const bool ok = gemm_epilogue_ext_ok(q, batch, &slots) && cfg != 80 && !(cfg >= 70 && cfg <= 73);
+    if (p.ln_stat) UG_REQUIRE(ok && !p.bias && p.ln_s && p.ln_bias, "LayerNorm fold: dense single-pass launch on a tile_epilogue kernel, N % 64 == 0, bias folded into ln_bias");
+    if (p.bias2_rows) UG_REQUIRE(ok && p.bias2 && !(p.flags & UG_F_GEGLU), "per-row bias2: dense single-pass launch on a tile_epilogue kernel");
+    if (p.row_part) {
+      if (ok && !(p.flags & UG_F_GEGLU)) *row_slots = slots; else p.row_part = nullptr;
+    }
   }
   launch_cfg(cfg, p, batch, s);
   if (split > 1) {

@@ -92,7 +92,10 @@ template <> struct HVec<4> { typedef f16x4 type; };
 
 // Per-tile epilogue shared by the GEMM kernels: the lane holds WID = 4*NT contiguous columns of rows
 // m0 + wm*WTM + i*16 + (lane & 15).  Clears the accumulators for the next tile.
-template <int MT, int NT, int WTM, int WTN>
+// EXT (round 5, compile-time so that the other instantiations keep their register allocation - as run-time branches these cost every GEMM kernel ~20 VGPRs,
+// an occupancy step on three tiles and 100 bytes of scratch in the 256 x 256 ones): LayerNorm fold (GemmP::ln_stat), row partial sums of the output
+// (GemmP::row_part), per-row-block bias2 (GemmP::bias2_rows).  launch_gemm sends a launch to an EXT instantiation only when one of the three is set.
+template <int MT, int NT, int WTM, int WTN, bool EXT = false>
 __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wm, int wn, int lane,
                                               long out_off) {
   constexpr int WID = 4 * NT;
@@ -122,9 +125,42 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][N
   const bool full = (nb + WID <= p.N);
   const bool vec = full && ((p.ldo & 7) == 0) && (!p.R1 || (p.ldr1 & 7) == 0) &&
                    (!p.R2 || (p.ldr2 & 7) == 0) && (OW % CH == 0);
+  const bool lnf = EXT && p.ln_stat != nullptr;   // LayerNorm folded into this GEMM (GemmP::ln_stat): whole column runs only (launch_gemm: N % 64 == 0)
+  if constexpr (EXT) {
+    // pass 1 of the fold, in place on the accumulators: acc <- rstd[m] (acc - mean[m] s[n]).  A separate pass so that s[] is dead before the bias / value /
+    // output registers of the epilogue proper are live (the 256 x 256 tiles have 128 accumulator registers per lane).
+    if (lnf && full) {
+      float sv[WID];
+#pragma unroll
+      for (int e = 0; e < WID; e += 4) {
+        const f32x4 sx = *(const f32x4*)(p.ln_s + nb + e);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sv[e + q] = sx[q];
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + l15;
+        float2 st = make_float2(0.f, 0.f);
+        if (m < p.M) st = p.ln_stat[m];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = st.y * (acc[i][j][r] - st.x * sv[j * 4 + r]);
+      }
+    }
+  }
   float bv[WID];
 #pragma unroll
   for (int e = 0; e < WID; ++e) bv[e] = 0.f;
+  if (lnf && full) {
+#pragma unroll
+    for (int e = 0; e < WID; e += 4) {
+      const f32x4 b = *(const f32x4*)(p.ln_bias + nb + e);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv[e + q] = b[q];
+    }
+  }
+  const bool b2row = EXT && p.bias2_rows > 0;     // bias2 is a per-row-block vector (added per row below)
   if (full) {
     if (p.bias) {
 #pragma unroll
@@ -134,7 +170,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][N
         for (int q = 0; q < CH; ++q) bv[e + q] += (float)b[q];
       }
     }
-    if (p.bias2) {
+    if (p.bias2 && !b2row) {
 #pragma unroll
       for (int e = 0; e < WID; e += CH) {
         const hvec b = *(const hvec*)(p.bias2 + nb + e);
@@ -170,6 +206,18 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][N
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (m >= p.M) continue;
+    if constexpr (EXT) {
+      if (b2row && full) {
+        const f16* b2 = p.bias2 + (long)(m / p.bias2_rows) * p.N + nb;
+#pragma unroll
+        for (int e = 0; e < WID; e += CH) {
+          const hvec b = *(const hvec*)(b2 + e);
+#pragma unroll
+          for (int q = 0; q < CH; ++q) v[e + q] += (float)b[q];
+        }
+      }
+    }
+    float rsum = 0.f, rsq = 0.f;               // GemmP::row_part: sum / sum of squares of the fp16 values this lane stores for row m
     if (geglu) {
       if (WID == 16) {
 #pragma unroll
@@ -217,7 +265,18 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][N
 #pragma unroll
           for (int q = 0; q < CH; ++q) h[q] = (f16)o[q];
           *(hvec*)((f16*)p.Out + out_off + orow * p.ldo + ob + e) = h;
+          if constexpr (EXT) {
+            if (p.row_part) {
+#pragma unroll
+              for (int q = 0; q < CH; ++q) { const float f = (float)h[q]; rsum += f; rsq += f * f; }
+            }
+          }
         }
+      }
+      if (EXT && p.row_part) {   // launch_gemm: only launches whose every in-range lane takes this fp16 vector path; the four lanes l15 + 16 g hold one row's 4 * WID columns of this wave
+        rsum += __shfl_xor(rsum, 16); rsq += __shfl_xor(rsq, 16);
+        rsum += __shfl_xor(rsum, 32); rsq += __shfl_xor(rsq, 32);
+        if (g == 0) p.row_part[(long)(n0 / WTN + wn) * p.M + m] = make_float2(rsum, rsq);
       }
     } else {
 #pragma unroll

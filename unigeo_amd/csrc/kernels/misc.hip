@@ -545,3 +545,27 @@ __global__ void k_normals(const float* depth, const float* K33, float* normals, 
 void launch_normals(const float* depth, const float* K33, float* normals, int T, int H, int W, hipStream_t s) {
   hipLaunchKernelGGL(k_normals, gs_grid((long)T * H * W), dim3(256), 0, s, depth, K33, normals, T, H, W);
 }
+
+// LayerNorm folded into the linear layer that consumes it (bind time, once): one wave per output row n.
+//   Wf[n][k] = fp16(W[n][k] * gamma[k]);  s[n] = sum_k float(Wf[n][k])  (the sums of the ROUNDED weights: what the MFMA multiplies);  bf[n] = bias[n] + sum_k beta[k] * W[n][k]
+// so that  LayerNorm(x) W^T + bias = rstd * (x Wf^T - mean * s) + bf.
+__global__ __launch_bounds__(256) void k_fold_ln_weights(const f16* W, const f16* bias, const f16* gamma, const f16* beta, f16* Wf, float* s_out, float* b_out, int N, int K) {
+  const int lane = threadIdx.x & 63;
+  const long n = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float w = (float)W[n * K + k];
+    const f16 wf = (f16)(w * (float)gamma[k]);
+    Wf[n * K + k] = wf;
+    s1 += (float)wf;
+    s2 += (float)beta[k] * w;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+  if (lane == 0) { s_out[n] = s1; b_out[n] = s2 + (bias ? (float)bias[n] : 0.f); }
+}
+void launch_fold_ln_weights(const f16* W, const f16* bias, const f16* gamma, const f16* beta, f16* Wf, float* s_out, float* b_out, int N, int K, hipStream_t s) {
+  hipLaunchKernelGGL(k_fold_ln_weights, dim3(cdiv(N, 4)), dim3(256), 0, s, W, bias, gamma, beta, Wf, s_out, b_out, N, K);
+  UG_CHECK(hipGetLastError());
+}

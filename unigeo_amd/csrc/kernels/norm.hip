@@ -662,6 +662,10 @@ __global__ __launch_bounds__(256) void ln_kernel(const LayerNormP p) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
   const float rstd = rsqrtf(var / p.C + p.eps);
+  if (p.stat_out) {   // statistics-only form: the consumer GEMM applies the normalisation in its epilogue (GemmP::ln_stat)
+    if (lane == 0) p.stat_out[row] = make_float2(mean, rstd);
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < VPL; ++k) {
     const int v = lane + k * 64;
@@ -706,5 +710,23 @@ void launch_layernorm(const LayerNormP& p, hipStream_t s) {
     case 3: hipLaunchKernelGGL(ln_kernel<3>, grid, block, 0, s, p); break;
     default: hipLaunchKernelGGL(ln_kernel<4>, grid, block, 0, s, p); break;
   }
+  UG_CHECK(hipGetLastError());
+}
+
+// (mean, rstd)[m] from the per-slot row sums a producing GEMM's epilogue wrote (GemmP::row_part, [slots][M]): the sums are those of the fp16 values stored,
+// so mean is exact to fp32 summation; var = E[x^2] - mean^2 is formed in double (the partial sums are fp32: with |mean| >> std the cancellation costs bits of
+// the sums themselves - fine for the residual streams of this network, where |mean| <~ std; the statistics-only LayerNorm launch is the exact alternative).
+__global__ __launch_bounds__(256) void k_rowstat_finalize(const float2* part, int slots, long M, int C, float eps, float2* stat) {
+  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int sl = 0; sl < slots; ++sl) { const float2 v = part[(long)sl * M + m]; s1 += (double)v.x; s2 += (double)v.y; }
+  const double mean = s1 / C;
+  const double var = fmax(s2 / C - mean * mean, 0.0);
+  stat[m] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+}
+void launch_rowstat_finalize(const float2* part, int slots, long M, int C, float eps, float2* stat, hipStream_t s) {
+  UG_REQUIRE(slots > 0 && M > 0, "rowstat_finalize: nothing to combine");
+  hipLaunchKernelGGL(k_rowstat_finalize, dim3(cdiv(M, 256)), dim3(256), 0, s, part, slots, M, C, eps, stat);
   UG_CHECK(hipGetLastError());
 }
