@@ -75,8 +75,9 @@ def test_vae_decode(tiny, T):
 
 @pytest.mark.parametrize("T,h,w,ln_fold", [(3, 8, 8, 1), (5, 8, 16, 1), (5, 8, 16, 2), (5, 8, 16, 0)])
 def test_unet_forward(tiny, T, h, w, ln_fold):
-    """ln_fold: 1 = the default (LayerNorms folded into their consumer GEMMs where it pays - at these sizes nowhere), 2 = folded wherever the kernels can
-    (every transformer block of the tiny configuration: row sums from the producing projections' epilogues, per-frame rows added there), 0 = LayerNorm launches."""
+    """ln_fold: 0 = LayerNorm launches (the default: the folded form measured +14 ms per clip), 1 = folded at M >= 4096 (at these sizes nowhere),
+    2 = folded wherever the kernels can (every transformer block of the tiny configuration: row sums from the producing projections' epilogues, per-frame rows
+    added there)."""
     rng = np.random.default_rng(3)
     u = tiny["cfgs"][0]
     x = h16(rng.standard_normal((T, u.in_channels, h, w)))
@@ -86,7 +87,7 @@ def test_unet_forward(tiny, T, h, w, ln_fold):
         tiny["eng"].set_ln_fold(ln_fold)
         got = tiny["eng"].unet_forward(x, tstep, emb)
     finally:
-        tiny["eng"].set_ln_fold(1)
+        tiny["eng"].set_ln_fold(0)
     with torch.no_grad():
         ref = tiny["unet"](torch.from_numpy(x)[None], torch.tensor(tstep), torch.from_numpy(emb)[None],
                            torch.tensor([[7.0, 127.0, 0.02]]))[0].numpy()
@@ -248,7 +249,7 @@ def test_full_architecture_unet_and_vae_decoder_small_clip():
         assert_close(got, ref, 3.5e-3, "full-architecture UNet forward")
         pipe.engine.set_ln_fold(2)           # round 5: every LayerNorm folded into its consumer GEMM wherever the kernels can (the clip's levels 1 / 2 run this way)
         got_f = pipe.engine.unet_forward(x, tstep, emb)
-        pipe.engine.set_ln_fold(1)
+        pipe.engine.set_ln_fold(0)
         assert_close(got_f, ref, 3.5e-3, "full-architecture UNet forward, LayerNorms folded into their consumers")
         report("full-architecture UNet: |fp16-storage oracle - fp32 oracle| / max", rel_err(ref16, ref))
         report("full-architecture UNet: |HIP - fp16-storage oracle| / max (the quantity north_star's 1e-3 bounds)", rel_err(got, ref16))

@@ -296,8 +296,8 @@ class Engine:
         else:
             self._ck(self.lib.ug_dc_run(self.ctx, int(steps), int(decode_chunk), int(bool(with_normals))))
 
-    def set_ln_fold(self, mode=1):
-        """LayerNorm folded into its consumer GEMM: 0 = LayerNorm launches (rounds 1 - 4), 1 = folded where it pays (default), 2 = wherever the kernels can."""
+    def set_ln_fold(self, mode=0):
+        """LayerNorm folded into its consumer GEMM: 0 = LayerNorm launches (default), 1 = folded at M >= 4096, 2 = wherever the kernels can."""
         self._ck(self.lib.ug_set_ln_fold(self.ctx, int(mode)))
 
     def op_proj_ln_linear(self, A, Wp, bp, gamma, beta, W, bias, R=None, vec=None, rows_per_vec=1, eps=1e-5, geglu=False, mode=2):

@@ -876,7 +876,7 @@ int ug_op_proj_ln_linear(ug_ctx* x, const float* A, int M, int K0, const float* 
         if (dvec) { l.addvec = dvec; l.rows_per_vec = rows_per_vec; l.Xout = s1; s_final = s1; }
         launch_layernorm(l, c.stream);
       }
-      pc.A0 = s_final; pc.W = wf; pc.ln_stat = stat; pc.ln_s = fs; pc.ln_bias = fb; pc.want_ext = 1; plan(pc);
+      pc.A0 = s_final; pc.W = wf; pc.ln_stat = stat; pc.ln_s = fs; pc.ln_bias = fb; pc.want_ext = 2; plan(pc);
       UG_REQUIRE(gemm_epilogue_ext_ok(pc, 1), "ug_op_proj_ln_linear: the consumer's tile cannot take the LayerNorm fold");
       launch_gemm(pc, 1, c.stream);
     }
@@ -981,6 +981,15 @@ int ug_bench_gemm(ug_ctx* x, int M, int N, int K, int conv, int T, int Hi, int W
     p.A0 = As[0]; p.A1 = A1s[0]; p.Out = Os[0];
     if (getenv("UG_BENCH_GEGLU") && !conv && N % 128 == 0) { p.flags |= UG_F_GEGLU; p.ldo = N / 2; }   // A/B aid: GEGLU epilogue
     if (getenv("UG_BENCH_R1")) { p.R1 = Os[nbuf - 1]; p.ldr1 = N; p.c1 = 1.f; }                          // A/B aid: a residual operand in the epilogue
+    if (getenv("UG_BENCH_NOBIAS")) p.bias = nullptr;
+    if (getenv("UG_BENCH_LNF") && !conv) {   // A/B aid: the LayerNorm-fold epilogue (GemmP::ln_stat) on dummy statistics - timing only
+      float2* st = (float2*)c.ws.get<float>((long)M * 2); float* ls = c.ws.get<float>(N); float* lb = c.ws.get<float>(N);
+      UG_CHECK(hipMemsetAsync(st, 0, (size_t)M * 8, c.stream)); UG_CHECK(hipMemsetAsync(ls, 0, (size_t)N * 4, c.stream)); UG_CHECK(hipMemsetAsync(lb, 0, (size_t)N * 4, c.stream));
+      p.bias = nullptr; p.ln_stat = st; p.ln_s = ls; p.ln_bias = lb; p.want_ext = 2;
+    }
+    float2* rpart = nullptr;
+    if (getenv("UG_BENCH_ROWPART") && !conv) { rpart = (float2*)c.ws.get<float>((long)M * 40 * 2); p.row_part = rpart; p.want_ext = 1; }   // ... the row partial sums (GemmP::row_part)
+    if (getenv("UG_BENCH_WANTEXT")) p.want_ext = 1;                                                       // ... only the planner's hint (tile choice without the extension)
     gemm_apply_tune(p, c.tune);
     int cf = cfg, sp = split;
     if (cf < 0 || sp < 1) { int c2, s2; gemm_plan(p, 1, &c2, &s2); if (cf < 0) cf = c2; if (sp < 1) sp = s2; }
@@ -988,10 +997,11 @@ int ug_bench_gemm(ug_ctx* x, int M, int N, int K, int conv, int T, int Hi, int W
     if (sp > 1) p.partial = c.ws.get<float>((long)sp * M * N);
     unsigned* trace = nullptr;
     if (getenv("UG_GEMM_TRACE")) { trace = c.ws.get<unsigned>(3 * 24 * 5); UG_CHECK(hipMemsetAsync(trace, 0, 3 * 24 * 5 * 4, c.stream)); p.trace = trace; }
-    for (int i = 0; i < 2; ++i) launch_gemm(p, 1, c.stream);
+    int rslots = 0;
+    for (int i = 0; i < 2; ++i) launch_gemm(p, 1, c.stream, nullptr, rpart ? &rslots : nullptr);
     hipEvent_t e0, e1; UG_CHECK(hipEventCreate(&e0)); UG_CHECK(hipEventCreate(&e1));
     UG_CHECK(hipEventRecord(e0, c.stream));
-    for (int i = 0; i < iters; ++i) { p.A0 = As[i % nbuf]; p.A1 = A1s[i % nbuf]; p.Out = Os[i % nbuf]; launch_gemm(p, 1, c.stream); }
+    for (int i = 0; i < iters; ++i) { p.A0 = As[i % nbuf]; p.A1 = A1s[i % nbuf]; p.Out = Os[i % nbuf]; launch_gemm(p, 1, c.stream, nullptr, rpart ? &rslots : nullptr); }
     UG_CHECK(hipEventRecord(e1, c.stream)); UG_CHECK(hipEventSynchronize(e1));
     float ms; UG_CHECK(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

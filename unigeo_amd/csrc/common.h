@@ -87,14 +87,16 @@ struct GemmP {
   // launch_gemm) and per column the sum / sum of squares of the fp16 values stored, stat_part[blk * N + n]; stat_hw = output rows per frame (blocks
   // must not straddle frames).  launch_gemm declines (reports rb = 0, writes nothing) when the chosen kernel cannot: split-K, ragged tiles, ...
   float2* stat_part; int stat_hw;
-  // LayerNorm folded into its consumer GEMM (round 5; dense launches through tile_epilogue only - launch_gemm checks): A is the RAW activation x, W holds
-  // W' = fp16(gamma o W0), and the epilogue turns acc = x W'^T into  rstd[m] * (acc - mean[m] * ln_s[n]) + ln_bias[n]  = LayerNorm(x) W0^T + bias  before
-  // GEGLU / c0 / residuals.  ln_stat[m] = (mean, rstd) of row m, ln_s[n] = sum_k W'[n][k], ln_bias[n] = bias[n] + sum_k beta[k] W0[n][k] (fp32; `bias` must be null).
+  // LayerNorm folded into its consumer GEMM (round 5; dense launches through tile_epilogue only - launch_gemm checks): A is the RAW activation x, W holds the
+  // centred folded weights Wf = fp16(gamma o W0 - rowmean(gamma o W0)) (k_fold_ln_weights: x Wf^T = (x - mean) (gamma o W0)^T), and the epilogue scales row m by
+  // rstd[m] = ln_stat[m].y and adds ln_bias[n] = bias[n] + sum_k beta[k] W0[n][k] (fp32; `bias` must be null) before GEGLU / c0 / residuals.  ln_s is not read
+  // by the kernels (the row sums the fp16 rounding leaves of Wf, ~1e-3: kept for the tests).
   const float2* ln_stat; const float* ln_s; const float* ln_bias;
   // Row statistics of the OUTPUT for the LayerNorm that follows (round 5): per row m and per slot = (column tile, wave column) the sum / sum of squares of
   // the fp16 values stored, row_part[slot * M + m]; launch_gemm reports the slot count (0 = the chosen kernel cannot: split-K, GEGLU, streaming / halo kernels).
   float2* row_part;
-  int want_ext;          // gemm_plan: pick a tile whose kernel is instantiated with these extensions (set by the caller that will set ln_stat / row_part / bias2_rows)
+  int want_ext;          // gemm_plan: pick a tile whose kernel is instantiated with these extensions (set by the caller that will set ln_stat / row_part / bias2_rows):
+                         // 1 = any of them, 2 = the LayerNorm fold alone (the 256 x 256 loader tile can then stay)
   int bias2_rows;        // 0: bias2 is one [N] vector; r > 0: output row m adds bias2[(m / r) * N + n] - the per-frame cross-attention row added to the residual stream
 };
 // tuning overrides (A/B tools and the tile-config tests; ug_tune_force sets them on ONE context, the engine copies them into every GemmP):
@@ -165,7 +167,7 @@ struct LayerNormP {
 void launch_layernorm(const LayerNormP& p, hipStream_t s);
 // (mean, rstd)[m] from the row partial sums a GEMM epilogue wrote (GemmP::row_part, [slots][M]); C = row length
 void launch_rowstat_finalize(const float2* part, int slots, long M, int C, float eps, float2* stat, hipStream_t s);
-// LayerNorm folded into a linear layer, at bind time: Wf[n][k] = fp16(W[n][k] * gamma[k]); s[n] = sum_k float(Wf[n][k]); bf[n] = bias[n] + sum_k beta[k] * W[n][k]
+// LayerNorm folded into a linear layer, at bind time: Wf[n][k] = fp16(W[n][k] * gamma[k] - rowmean_n); s[n] = sum_k float(Wf[n][k]) (~0); bf[n] = bias[n] + sum_k beta[k] * W[n][k]
 void launch_fold_ln_weights(const f16* W, const f16* bias, const f16* gamma, const f16* beta, f16* Wf, float* s_out, float* b_out, int N, int K, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------

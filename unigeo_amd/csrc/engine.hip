@@ -322,15 +322,15 @@ static void linear(Ctx& c, const f16* A, long M, const Lin& l, f16* out, const E
   p.Out = out; p.ldo = ldo ? ldo : nout;
   if (p.R1 && !p.ldr1) p.ldr1 = nout;
   if (p.R2 && !p.ldr2) p.ldr2 = nout;
-  p.want_ext = (e.ln_stat || e.rs || e.bias2_rows > 0) ? 1 : 0;
+  p.want_ext = (e.rs || e.bias2_rows > 0) ? 1 : (e.ln_stat ? 2 : 0);
   run_gemm(c, p, 1, e.ln_stat ? "gemm_linear_lnf" : "gemm_linear", e.alg, e.so, e.stat_hw, e.rs);
 }
 // would linear(A[M, l.in], l, flags) take the round-5 epilogue extensions (LayerNorm fold, row partial sums, per-row bias2) on the tile the planner picks?
-static bool lin_ext_ok(Ctx& c, long M, const Lin& l, int flags) {
+static bool lin_ext_ok(Ctx& c, long M, const Lin& l, int flags, int want = 1) {
   GemmP p; memset(&p, 0, sizeof(p));
   p.C0 = l.in; p.M = (int)M; p.N = l.out; p.K = l.in; p.ldw = l.in; p.flags = flags; p.nb_inner = 1;
   const int nout = (flags & UG_F_GEGLU) ? l.out / 2 : l.out;
-  p.ldo = nout; p.ldr1 = nout; p.ldr2 = nout; p.c0 = 1.f; p.want_ext = 1;
+  p.ldo = nout; p.ldr1 = nout; p.ldr2 = nout; p.c0 = 1.f; p.want_ext = want;
   gemm_apply_tune(p, c.tune);
   return gemm_epilogue_ext_ok(p, 1);
 }
@@ -1096,7 +1096,7 @@ static f16* transformer_forward(Ctx& c, const Transformer& tr, const f16* x, int
   // statistics-only LayerNorm launch.  The cross-attention row is added by the producing projection (GemmP::bias2_rows) instead of by the LayerNorm pass.
   // Ctx::ln_fold: 0 off, 1 where it pays (M >= 4096), 2 wherever the kernels can (tests).  Narrow level: the fused feed-forward / streaming forms keep their own.
   auto fold_site = [&](const Lin& l, int flags) {
-    return c.ln_fold && !q8 && l.wf && (c.ln_fold >= 2 || M >= 4096) && lin_ext_ok(c, M, l, flags);
+    return c.ln_fold && !q8 && l.wf && (c.ln_fold >= 2 || M >= 4096) && lin_ext_ok(c, M, l, flags, 2);
   };
   // ---- spatial block
   f16* qkv = c.ws.get<f16>(M * 3 * C);
