@@ -311,6 +311,11 @@ def main():
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "config0", "sample"],
                     help="config0 = BASELINE configs[0] as stated (25 frames 384x512, 2 Euler steps on the host cores: ~3-4 min on 32 threads); "
                          "sample = a 3-frame 192x256 clip (~10 s) extrapolated by algorithmic work; auto = config0 with >= 16 host cores")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="independent clips in flight per GPU (round 5): that many engine contexts, each with its own weights replica, workspace, HIP stream and "
+                         "host thread; clip i of a rank runs on context i %% in_flight.  Clips are independent samples (reference eval.py:33-56), so this is the "
+                         "same sharding as over GPUs, one level down: a second clip fills the CUs that one clip's tile tails and under-filled launches leave idle "
+                         "(+10 %% aggregate, tools/two_clips_in_flight.py).  1 = one clip at a time (also always reported as value_one_clip_at_a_time)")
     ap.add_argument("--lanes", type=int, default=1, help="independent chunks (VAE encode / decode chunks, CLIP) in flight on separate HIP streams; 1 = serial")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the with-normals / N=5 / fp16-encoder / fp8 side rates (rocprofv3 runs)")
@@ -346,37 +351,86 @@ def main():
     from unigeo_amd.model.depthcrafter import DepthCrafter
 
     T, H, W = a.frames, a.height, a.width
-    if a.tiny:
-        from unigeo_amd import weights as Wt
-        pipe = DepthCrafterPipelineHIP.from_random(seed=42, cfgs=Wt.tiny_cfgs(), device_id=local, workspace_bytes=3 << 30)
-    else:
-        pipe = DepthCrafterPipelineHIP.from_random(seed=42, device_id=local, workspace_bytes=40 << 30)
-    eng = pipe.engine
+    nctx = max(1, min(a.in_flight, a.steps)) if not a.fp8 else 1
+    pipes = []
+    for j in range(nctx):
+        if a.tiny:
+            from unigeo_amd import weights as Wt
+            pipes.append(DepthCrafterPipelineHIP.from_random(seed=42, cfgs=Wt.tiny_cfgs(), device_id=local, workspace_bytes=3 << 30))
+        else:
+            pipes.append(DepthCrafterPipelineHIP.from_random(seed=42, device_id=local, workspace_bytes=(40 << 30) if j == 0 else (12 << 30)))
+    engs = [p_.engine for p_ in pipes]
+    pipe, eng = pipes[0], engs[0]
     if a.fp8:
         eng.set_fp8_linears(True)
-    eng.set_concurrency(a.lanes)
-    clip = synthetic_clip(T, H, W, seed=1234 + rank)
-    frames = DepthCrafter.prepare_input(None, clip)
-    nl, na = make_noise(T, H, W, seed=rank)
-    K = np.stack(clip["intrinsics"], 0)
-    eng.set_inputs(frames, nl, na, K)                     # inputs resident in HBM before the timed region
+    inputs = []
+    for j, e in enumerate(engs):
+        e.set_concurrency(a.lanes)
+        clip_j = synthetic_clip(T, H, W, seed=1234 + rank * nctx + j)
+        fr_j = DepthCrafter.prepare_input(None, clip_j)
+        nl_j, na_j = make_noise(T, H, W, seed=rank * nctx + j)
+        K_j = np.stack(clip_j["intrinsics"], 0)
+        e.set_inputs(fr_j, nl_j, na_j, K_j)               # inputs resident in HBM before the timed region
+        inputs.append((fr_j, nl_j, na_j, K_j))
+    frames, nl, na, K = inputs[0]
 
+    import threading
     t_clip, t_gather = [], []                              # per-clip wall of this rank: the engine call / the all_gather (N > 1)
 
-    def one_clip():
-        t_a = time.perf_counter()
-        eng.run(a.denoise_steps, 8, with_normals=False)   # returns after its own stream sync
+    def gather_depth(e):                                   # reassemble outputs: RCCL all_gather over xGMI (main thread only: collectives keep one order on every rank)
         t_b = time.perf_counter()
-        if multi:                                          # reassemble outputs: RCCL all_gather over xGMI
-            ptr, shape = eng.device_ptrs()["depth"]
-            local_t = torch.as_tensor(DeviceArray(ptr, shape), device=f"cuda:{local}")
-            out = [torch.empty_like(local_t) for _ in range(world)]
-            dist.all_gather(out, local_t)
-            torch.cuda.current_stream().synchronize()      # the next run overwrites the engine's depth buffer
-        t_clip.append((t_b - t_a) * 1e3); t_gather.append((time.perf_counter() - t_b) * 1e3)
+        ptr, shape = e.device_ptrs()["depth"]
+        local_t = torch.as_tensor(DeviceArray(ptr, shape), device=f"cuda:{local}")
+        out = [torch.empty_like(local_t) for _ in range(world)]
+        dist.all_gather(out, local_t)
+        torch.cuda.current_stream().synchronize()          # the context's next run overwrites its depth buffer
+        t_gather.append((time.perf_counter() - t_b) * 1e3)
 
-    for _ in range(a.warmup):
-        one_clip()
+    def run_clips(n):
+        """n clips of this rank, clip i on context i % nctx, up to nctx in flight.  Every context has a host thread that runs its clips back to back; with
+        N > 1 the main thread gathers each finished clip's depth in clip order (the same order on every rank) before that context starts its next clip."""
+        if nctx == 1:
+            for _ in range(n):
+                t_a = time.perf_counter()
+                eng.run(a.denoise_steps, 8, with_normals=False)   # returns after its own stream sync
+                t_clip.append((time.perf_counter() - t_a) * 1e3)
+                if multi:
+                    gather_depth(eng)
+            return
+        done = [threading.Event() for _ in range(n)]
+        gathered = [threading.Event() for _ in range(n)]
+        errs = []
+
+        def worker(j):
+            try:
+                for i in range(j, n, nctx):
+                    t_a = time.perf_counter()
+                    engs[j].run(a.denoise_steps, 8, with_normals=False)
+                    t_clip.append((time.perf_counter() - t_a) * 1e3)
+                    done[i].set()
+                    if multi:
+                        gathered[i].wait()
+            except Exception as ex:       # surface in the main thread
+                errs.append(ex)
+                for ev in done:
+                    ev.set()
+        th = [threading.Thread(target=worker, args=(j,)) for j in range(min(nctx, n))]
+        [t_.start() for t_ in th]
+        for i in range(n):
+            done[i].wait()
+            if errs:
+                break
+            if multi:
+                gather_depth(engs[i % nctx])
+                gathered[i].set()
+        for ev in gathered:
+            ev.set()
+        [t_.join() for t_ in th]
+        if errs:
+            raise errs[0]
+
+    if a.warmup > 0:
+        run_clips(max(a.warmup, nctx) if nctx > 1 else a.warmup)     # every context warm (first-launch attribute calls, clocks)
     t_clip.clear(); t_gather.clear()
     if multi:
         dist.barrier()
@@ -385,8 +439,7 @@ def main():
     if smi:
         smi.__enter__()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        one_clip()
+    run_clips(a.steps)
     if multi:
         dist.barrier()
     torch.cuda.synchronize() if torch.cuda.is_available() else None
@@ -402,6 +455,14 @@ def main():
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [[round(float(v), 2) for v in r.tolist()] for r in allr]
+    value_one = None
+    if nctx > 1 and rank == 0 and not multi:               # the same binary, one clip at a time (3 clips on context 0), right after the timed region
+        t1 = time.perf_counter()
+        for _ in range(3):
+            eng.run(a.denoise_steps, 8, with_normals=False)
+        value_one = 3 * T / (time.perf_counter() - t1)
+    for e in engs[1:]:                                      # the side rates and probes below use context 0 alone
+        e.close()
 
     if rank == 0:
         ms = dt / a.steps * 1000.0
@@ -411,13 +472,19 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "fp8 (MX e4m3, e8m0 block scales) linear layers + fp16" if a.fp8 else "fp16",
                "data": "synthetic (seeded frames + noise, seeded random weights of the SVD-XT/DepthCrafter architecture)",
-               "config": {"workload": f"DepthCrafter SVD-UNet {'MX-fp8 linear layers + fp16' if a.fp8 else 'fp16'}, {a.denoise_steps}-step Euler, one {T}-frame {H}x{W} clip per GPU "
+               "config": {"workload": f"DepthCrafter SVD-UNet {'MX-fp8 linear layers + fp16' if a.fp8 else 'fp16'}, {a.denoise_steps}-step Euler, {T}-frame {H}x{W} clips "
                                       + ("(BASELINE configs[1])" if (T, H, W, a.denoise_steps, a.fp8, a.tiny) == (25, 384, 512, 25, False, False) else
                                          "(BASELINE configs[4] geometry)" if (T, H, W) == (50, 576, 768) else "(NOT a BASELINE configuration)")
                                       + "; CLIP + VAE enc/dec + depth post-proc inside the timed region",
                           "clips_per_gpu_timed": a.steps, "frames": T, "height": H, "width": W,
                           "denoise_steps": a.denoise_steps, "parallelism": f"clip-sharded x{world}, RCCL all_gather of depth",
-                          "lanes": a.lanes}}
+                          "clips_in_flight_per_gpu": nctx, "lanes": a.lanes}}
+        if nctx > 1:
+            res["config"]["workload"] += (f"; {nctx} independent clips in flight per GPU ({nctx} engine contexts / HIP streams / host threads, clip i on context i % {nctx}): "
+                                          "value = all timed clips / wall, ms_per_step = wall / clips (a clip's own latency is about "
+                                          f"{nctx} x ms_per_step x 0.9); value_one_clip_at_a_time = the same binary with one clip in flight")
+            if value_one is not None:
+                res["value_one_clip_at_a_time"] = round(value_one, 3)
         res["per_rank_ms"] = {"columns": ["clip_mean", "clip_max", "gather_mean", "gather_max"],
                               "ranks": per_rank if per_rank is not None else [[round(float(np.mean(t_clip)), 2), round(float(np.max(t_clip)), 2), 0.0, 0.0]],
                               "host_affinity": affinity}
