@@ -45,3 +45,9 @@ def test_evaluate_loop(tmp_path):
     r0, _ = evaluate(CFG, dataset=ds, model=_GTModel(), save_dir=str(tmp_path / "r0"), rank=0, world=2, verbose=False)
     r1, _ = evaluate(CFG, dataset=ds, model=_GTModel(), save_dir=str(tmp_path / "r1"), rank=1, world=2, verbose=False)
     assert sorted(x["seq_name"] for x in r0 + r1) == sorted(x["seq_name"] for x in rows)
+    # two plugin instances on one GPU, clips in flight on two host threads (round 5): same rows in the same order, same CSV
+    ds5 = SyntheticGeometryDataset(**parse_dataset_config(CFG), num_frames=21)
+    ra, _ = evaluate(CFG, dataset=ds5, model=_GTModel(), save_dir=str(tmp_path / "a"), verbose=False)
+    rb, _ = evaluate(CFG, dataset=ds5, models=[_GTModel(), _GTModel()], save_dir=str(tmp_path / "b"), verbose=False)
+    assert len(ra) == len(ds5) >= 5 and ra == rb
+    assert (tmp_path / "a" / "metrics.csv").read_text() == (tmp_path / "b" / "metrics.csv").read_text()

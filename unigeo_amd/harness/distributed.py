@@ -12,14 +12,14 @@ from .eval import evaluate, parse_metric_config
 from .metrics import MetricsManager
 
 
-def evaluate_sharded(config, dataset, model, save_dir="./debug_output", dist=None, verbose=False):
+def evaluate_sharded(config, dataset, model, save_dir="./debug_output", dist=None, verbose=False, models=None):
     if dist is None or not dist.is_initialized():
         rank, world = 0, 1
     else:
         rank, world = dist.get_rank(), dist.get_world_size()
     t0 = time.perf_counter()
     rows, _ = evaluate(config, dataset=dataset, model=model, save_dir=os.path.join(save_dir, f"rank{rank}"),
-                       rank=rank, world=world, verbose=verbose)
+                       rank=rank, world=world, verbose=verbose, models=models)     # models: several plugin instances on this rank's GPU, clips in flight (eval.py)
     t_eval = time.perf_counter() - t0
     timing = {"world": world, "per_rank": [{"rank": rank, "clips": len(rows), "eval_s": round(t_eval, 3)}], "gather_s": 0.0, "barrier_wait_s": 0.0}
     if world > 1 or (dist is not None and dist.is_initialized()):

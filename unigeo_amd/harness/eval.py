@@ -34,28 +34,30 @@ def parse_metric_config(config):
 
 
 def evaluate(config, dataset=None, model=None, save_dir="./debug_output", rank=0, world=1, verbose=True,
-             device_metrics=False):
+             device_metrics=False, models=None):
     """Run the reference's per-clip loop.  With ``world > 1`` this rank only evaluates clips
     ``rank, rank+world, ...`` (clips are independent samples); rows are merged by the caller.
     ``device_metrics=True`` evaluates depth / normal metrics on the GPU against the outputs still resident in HBM
-    (``ug_eval_depth`` / ``ug_eval_normal``) instead of on the host copies."""
+    (``ug_eval_depth`` / ``ug_eval_normal``) instead of on the host copies.
+    ``models`` = several instances of the plugin on ONE GPU (round 5): this rank's k-th clip runs on ``models[k % len(models)]``, each instance on its own host
+    thread - independent clips in flight on one GPU, the sharding over GPUs one level down (+10 % aggregate frames/s with two DepthCrafter contexts: a second
+    clip fills the CUs that one clip's tile tails and under-filled launches leave idle).  Rows / CSV come out in dataset order, identical to the serial loop."""
     if dataset is None:
         dataset = import_class_from_module("unigeo_amd.harness", config["dataset"])(**parse_dataset_config(config))
-    if model is None:
+    if model is None and not models:
         model = import_class_from_module("unigeo_amd.model", config["model_name"])(**config["model_params"])
     mm = MetricsManager(metric_names=parse_metric_config(config))
     os.makedirs(save_dir, exist_ok=True)
     save_path = os.path.join(save_dir, "metrics.csv")
-    rows = []
-    for data_idx in range(rank, len(dataset), world):
+    def one_clip(data_idx, mdl):
         data = dataset[data_idx]
         seq = f"{data_idx:03d}_{data['scene_name']}"
         if verbose:
             print("processing seq:", seq)
-        output = model.forward(data)
+        output = mdl.forward(data)
         gt = prepare_gt_label(data)
         metric = {"seq_name": seq}
-        eng = getattr(getattr(model, "pipeline", None), "engine", None) if device_metrics else None
+        eng = getattr(getattr(mdl, "pipeline", None), "engine", None) if device_metrics else None
         if "eval_depth" in config:
             if eng is not None:
                 res = eng.eval_depth(gt["gt_depths"].numpy(), gt["gt_masks"].numpy())
@@ -67,6 +69,31 @@ def evaluate(config, dataset=None, model=None, save_dir="./debug_output", rank=0
                 metric.update(eng.eval_normal(gt["gt_normals"].numpy(), gt["gt_masks"].numpy()))
             else:
                 metric.update(normal_evaluation(output["pred_normals"], gt["gt_normals"], custom_mask=gt["gt_masks"]))
+        return metric
+
+    mine = list(range(rank, len(dataset), world))
+    rows = []
+    if models and len(models) > 1:
+        import threading
+        out, errs = [None] * len(mine), []
+
+        def worker(j):
+            try:
+                for k in range(j, len(mine), len(models)):
+                    out[k] = one_clip(mine[k], models[j])
+            except Exception as ex:
+                errs.append(ex)
+        th = [threading.Thread(target=worker, args=(j,)) for j in range(len(models))]
+        [t.start() for t in th]; [t.join() for t in th]
+        if errs:
+            raise errs[0]
+        for metric in out:                     # dataset order, as the serial loop writes them
+            rows.append(metric)
+            mm.update_metrics(metric)
+        mm.export_to_csv(save_path)
+        return rows, mm
+    for data_idx in mine:
+        metric = one_clip(data_idx, models[0] if models else model)
         rows.append(metric)
         mm.update_metrics(metric)
         mm.export_to_csv(save_path)
