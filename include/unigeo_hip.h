@@ -103,6 +103,12 @@ int ug_set_vae_encode_fp32(ug_ctx* ctx, int on);
  * separate HIP streams - one chunk's HBM-bound passes overlap another's MFMA-bound ones.  Same kernels, same launch parameters:
  * outputs are bit-identical for every setting. */
 int ug_set_concurrency(ug_ctx* ctx, int lanes);
+/* Two (or more) contexts on ONE GPU, each running its own clip (round 5): the reference's evaluation loop handles one independent clip after the other
+ * (eval.py:33-56: `for data_idx ...: output = model.forward(data)`), so a second plugin instance on the same GPU can process the next clip meanwhile - its
+ * kernels fill the CUs that one clip's tile tails and under-filled launches leave idle (+10 % aggregate frames/s).  on = 1 tells a context that it shares the
+ * GPU: heuristics that pay extra launches / work to fill the last round of ONE kernel are dropped (the fused feed-forward takes all rows, the tile planner
+ * ignores the last-round fill).  Same arithmetic per layer up to the tile choice (all tiles are bit-identical, tests/test_ops_gpu.py).  Default 0. */
+int ug_set_coscheduled(ug_ctx* ctx, int on);
 /* BASELINE configs[4] (north_star: "fp8 MFMA ... (CDNA4 fp8)"): on = 1 runs the UNet transformers' linear layers whose K is a multiple
  * of 128 on MX-fp8 matrix instructions (v_mfma_scale_f32_16x16x128_f8f6f4: OCP e4m3 elements, one e8m0 power-of-two scale per 32
  * K elements; activations are quantised on the fly, weights once at bind time).  Reduced precision - the reference has no fp8 path;

@@ -279,7 +279,7 @@ def test_multi_gpu_entry_points_run_under_a_single_rank_rccl_group(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])          # the JSON line must be the LAST line of stdout (driver contract)
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak" and "all_gather" in line["config"]["parallelism"]
-    assert line["config"]["clips_in_flight_per_gpu"] == 2      # round 5: two engine contexts per rank, the gathers issued in clip order from the main thread
+    assert line["config"]["clips_in_flight_per_gpu"] == 2      # round 5: min(--in-flight, --steps) engine contexts per rank, the gathers issued in clip order from the main thread
     cfg = tmp_path / "cfg.yaml"
     cfg.write_text(textwrap.dedent("""
         dataset: "SyntheticGeometryDataset"

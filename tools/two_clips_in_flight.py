@@ -18,6 +18,10 @@ for i in range(n):
     clip = synthetic_clip(T, H, W, seed=1234 + i)
     nl, na = make_noise(T, H, W, i)
     pipe.engine.set_inputs(DepthCrafter.prepare_input(None, clip), nl, na, np.stack(clip["intrinsics"], 0))
+    if os.environ.get("UG_TUNE_KNOBS"):     # GEMM knob mask (kernels/gemm.hip) for every context
+        pipe.engine.tune_force(-100 - int(os.environ["UG_TUNE_KNOBS"]), -1)
+    if os.environ.get("UG_COSCHED"):
+        pipe.engine.set_coscheduled(True)
     pipe.engine.run(25, 8)
     engs.append(pipe.engine)
 t0 = time.perf_counter()

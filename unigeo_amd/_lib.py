@@ -18,7 +18,7 @@ EXPORTS = [
     "ug_unet_config_default", "ug_vae_config_default", "ug_clip_config_default",
     "ug_create", "ug_destroy", "ug_last_error", "ug_workspace_peak",
     "ug_load_tensor", "ug_bind_unet", "ug_bind_vae", "ug_bind_clip",
-    "ug_dc_set_inputs", "ug_dc_run", "ug_dc_run_windows", "ug_dc_get_outputs", "ug_dc_device_ptrs", "ug_dc_set_trace", "ug_set_vae_encode_fp32", "ug_set_concurrency", "ug_set_fp8_linears", "ug_op_linear_mx8", "ug_set_ff_fused", "ug_set_ln_fold", "ug_op_proj_ln_linear", "ug_op_ff", "ug_op_ln_ff", "ug_bench_ff", "ug_bench_flash", "ug_tune_flash", "ug_tune_ff",
+    "ug_dc_set_inputs", "ug_dc_run", "ug_dc_run_windows", "ug_dc_get_outputs", "ug_dc_device_ptrs", "ug_dc_set_trace", "ug_set_vae_encode_fp32", "ug_set_concurrency", "ug_set_coscheduled", "ug_set_fp8_linears", "ug_op_linear_mx8", "ug_set_ff_fused", "ug_set_ln_fold", "ug_op_proj_ln_linear", "ug_op_ff", "ug_op_ln_ff", "ug_bench_ff", "ug_bench_flash", "ug_tune_flash", "ug_tune_ff",
     "ug_eval_depth", "ug_eval_normal", "ug_clip_embed", "ug_vae_encode", "ug_vae_decode", "ug_unet_forward", "ug_normals_from_depth",
     "ug_op_linear", "ug_op_conv", "ug_op_conv_gn", "ug_op_groupnorm", "ug_op_layernorm", "ug_op_flash_attn",
     "ug_op_temporal_attn", "ug_op_attention_generic", "ug_op_flash_attn_dh", "ug_op_euler_step",
@@ -84,6 +84,7 @@ def load_library():
     try:
         lib.ug_set_fp8_linears.argtypes = [vp, ip]
         lib.ug_set_concurrency.argtypes = [vp, ip]
+        lib.ug_set_coscheduled.argtypes = [vp, ip]
         lib.ug_set_ff_fused.argtypes = [vp, ip]
         lib.ug_set_ln_fold.argtypes = [vp, ip]
         lib.ug_op_proj_ln_linear.argtypes = [vp, vp, ip, ip, vp, vp, ip, vp, vp, ip, vp, vp, C.c_float, vp, vp, ip, ip, ip, vp, vp, vp]
@@ -295,6 +296,11 @@ class Engine:
             self._ck(self.lib.ug_dc_run_windows(self.ctx, int(steps), int(decode_chunk), int(bool(with_normals)), int(window), int(overlap)))
         else:
             self._ck(self.lib.ug_dc_run(self.ctx, int(steps), int(decode_chunk), int(bool(with_normals))))
+
+    def set_coscheduled(self, on=True):
+        """This context shares the GPU with another clip in flight (a second context): drop the heuristics that fill the last round of one kernel at the
+        price of extra launches / work (fused feed-forward tail split, last-round fill factor of the tile planner)."""
+        self._ck(self.lib.ug_set_coscheduled(self.ctx, int(bool(on))))
 
     def set_ln_fold(self, mode=0):
         """LayerNorm folded into its consumer GEMM: 0 = LayerNorm launches (default), 1 = folded at M >= 4096, 2 = wherever the kernels can."""

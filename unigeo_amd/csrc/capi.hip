@@ -130,6 +130,13 @@ int ug_set_ff_fused(ug_ctx* x, int on) {
   x->c.ff_fused = on & 3; x->c.lane_need.clear();   // bit 0: fused feed-forward kernel, bit 1: its pre-LayerNorm inside the kernel  (a feature toggle changes the transient memory a lane task needs) LayerNorm -> Q|K|V projection
   return 0;
 }
+int ug_set_coscheduled(ug_ctx* x, int on) {
+  if (!x) return -1;
+  x->c.cosched = on ? 1 : 0;
+  if (on) x->c.tune.knobs |= 4194304; else x->c.tune.knobs &= ~4194304;      // gemm_plan: no last-round fill factor
+  x->c.lane_need.clear();
+  return 0;
+}
 int ug_set_ln_fold(ug_ctx* x, int mode) {
   if (!x) return -1;
   x->c.ln_fold = mode < 0 ? 0 : (mode > 2 ? 2 : mode); x->c.lane_need.clear();

@@ -170,6 +170,8 @@ struct Ctx {
                              // register file of every CU, so a second stream's kernels only get the tail rounds
   std::map<std::string, size_t> lane_need;
   int cur_lane = 0;          // 0 = main stream, l + 1 = lane l (run_lanes)
+  int cosched = 0;           // this context shares the GPU with another clip in flight (ug_set_coscheduled): heuristics that trade extra launches / work for a fuller
+                             // last round of ONE kernel are off - the fused feed-forward takes all rows (no two-GEMM tail), the tile planner ignores the last-round fill
   int ln_fold = 0;           // LayerNorm folded into its consumer GEMM (engine.hip: transformer_forward): 0 off (default: measured +14 ms per clip), 1 at M >= 4096, 2 wherever the kernels can (tests)
   int ff_variant = 0, flash_variant = -1;   // ug_tune_ff / ug_tune_flash: per-context A/B overrides copied into FFusedP / FlashP (0 / -1 = the defaults)
   GemmTune tune;             // ug_tune_force: tile-config / split-K / knob overrides for THIS context's GEMM launches (tests, A/B tools)

@@ -997,9 +997,11 @@ struct PreNorm { const f16* g; const f16* b; float eps; const f16* addvec; long 
 // 176 CUs: 59.9 us against 55.2 + the LayerNorm launch for 11264 rows, bit-identical, 961.7 vs 961.1 ms per clip - every workgroup streams the whole
 // 4.9 MB of W1 | W2 whatever its row count, so halving the rows does not halve the tile.  No gain, removed.  Likewise a persistent grid of 200 workgroups
 // x 3 tiles instead of 256 x 2 + the tail launches: 951.5 against 944 ms per clip - a tile costs the same whether 200 or 256 run beside it.)
-static long ff_fused_rows(long M) {
+static long ff_fused_rows(const Ctx& c, long M) {
   const long ntile = (M + 127) / 128, full = ntile / 256 * 256, rem = ntile - full;
-  return (full > 0 && rem > 0 && rem <= 160 && !getenv("UG_FF_NOSPLIT")) ? full * 128 : M;
+  static const bool nosplit = getenv("UG_FF_NOSPLIT") != nullptr;
+  // (co-scheduled contexts: the CUs a thin last round leaves idle run the other clip's kernels - one launch for all rows, 28.4 -> 28.7 frames/s with two clips in flight)
+  return (full > 0 && rem > 0 && rem <= 160 && !nosplit && !c.cosched) ? full * 128 : M;
 }
 static void ff_pair(Ctx& c, const f16* a, long M, const Lin& f1, const Lin& f2, f16* mid, f16* out, const Epi& e2, const QAct* q = nullptr,
                     const PreNorm* pre = nullptr, bool no_fuse = false) {
@@ -1051,7 +1053,7 @@ static void ln_ff(Ctx& c, const f16* x, long M, const Norm& ln, const f16* addve
                   const Lin& f1, const Lin& f2, f16* mid, f16* out, const Epi& e2, const QAct* q) {
   const int C = f2.out;
   if ((c.ff_fused & 2) && ff_pair_fusable(c, M, f1, f2, e2) && ln.g && ln.b && e2.R1 == (addvec ? xout : x) && (!addvec || xout)) {
-    const long M1 = ff_fused_rows(M);     // whole rounds of the fused kernel ...
+    const long M1 = ff_fused_rows(c, M);     // whole rounds of the fused kernel ...
     Epi e = e2; e.R1 = x;
     const PreNorm pre = {ln.g, ln.b, ln.eps, addvec, rows_per_vec};
     ff_pair(c, x, M1, f1, f2, mid, out, e, nullptr, &pre);
@@ -1065,7 +1067,7 @@ static void ln_ff(Ctx& c, const f16* x, long M, const Norm& ln, const f16* addve
   }
   layernorm(c, x, M, ln, t1, addvec, rows_per_vec, xout, q);
   if (ff_pair_fusable(c, M, f1, f2, e2)) {
-    const long M1 = ff_fused_rows(M), o = M1 * C;
+    const long M1 = ff_fused_rows(c, M), o = M1 * C;
     ff_pair(c, t1, M1, f1, f2, mid, out, e2, q);
     if (M1 < M) {
       Epi et = e2; if (et.R1) et.R1 += o; if (et.R2) et.R2 += o;

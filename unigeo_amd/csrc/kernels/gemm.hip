@@ -1246,8 +1246,10 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
     if (geglu && !c.geglu_ok) continue;
     const long tm = cdiv(p.M, c.bm), tn = cdiv(p.N, c.bn);
     const long tiles = tm * tn * batch, slots = (long)c.percu * 256;
-    float sc = (p.conv ? c.conv : c.dense) * ((float)p.M / (tm * c.bm)) * ((float)p.N / (tn * c.bn)) *
-               ((float)tiles / (cdiv(tiles, slots) * slots));
+    // knob 4194304 (round 5): this context shares the GPU with another clip in flight - the CUs a thin last round leaves idle are not lost, the other
+    // stream's kernels run on them: score the tiles without the last-round fill factor
+    const float fill = (p.tune_knobs & 4194304) ? 1.f : (float)tiles / (cdiv(tiles, slots) * slots);
+    float sc = (p.conv ? c.conv : c.dense) * ((float)p.M / (tm * c.bm)) * ((float)p.N / (tn * c.bn)) * fill;
     if (c.id == 19 && p.conv && p.K <= 512) sc *= 1.25f;   // its 3-stage ring hides the short K loop's fill (temporal convs, K = 3C); in-situ it loses on dense K = 320
     // in situ the five-step K loops of level 0 (K = 320, operand fresh in the Infinity Cache) run ~8 % better on the smaller tiles than on
     // 256x256 (76800x960x320: 82 vs 90 us); the GEGLU projection (N = 2560) stays on 256x256 (184 vs 201 us)
