@@ -22,6 +22,10 @@ for i in range(n):
         pipe.engine.tune_force(-100 - int(os.environ["UG_TUNE_KNOBS"]), -1)
     if os.environ.get("UG_COSCHED"):
         pipe.engine.set_coscheduled(True)
+    if os.environ.get("UG_COSCHED_KNOBS"):   # extra knob bits on top of the co-scheduled ones (A/B)
+        pipe.engine.tune_force(-100 - (4194304 | int(os.environ["UG_COSCHED_KNOBS"])), -1)
+    if os.environ.get("UG_TUNE_SPLIT"):
+        pipe.engine.tune_force(-1, int(os.environ["UG_TUNE_SPLIT"]))
     pipe.engine.run(25, 8)
     engs.append(pipe.engine)
 t0 = time.perf_counter()
