@@ -230,16 +230,37 @@ def cpu_baseline_stablenormal(threads):
             "sample_wall_s": round(wall, 2), "weight_init_s": round(t_init, 1)}
 
 
+def sn_images_in_flight(preds, img, reps):
+    """images/s of len(preds) StableNormal predictor contexts on one GPU, each on its own host thread, one image per call (tools/sn_images_in_flight.py)."""
+    import threading
+
+    def work(p_):
+        for _ in range(reps):
+            p_.predict_batch(img)
+    th = [threading.Thread(target=work, args=(p_,)) for p_ in preds]
+    t0 = time.perf_counter()
+    [t_.start() for t_ in th]; [t_.join() for t_ in th]
+    return len(preds) * reps / (time.perf_counter() - t0)
+
+
 def bench_stablenormal(a):
     """BASELINE configs[3]: StableNormal on 576x576 images (reference model/stablenormal.py:39 calls the predictor once per frame, so
     the headline is batch 1; the batched rate - the frames of a clip as one ug_sn_run call - is reported beside it).  One JSON line."""
-    import torch  # noqa: F401  (device runtime warm-up parity with the main workload)
+    # (no `import torch` here: with torch loaded first libunigeo_hip.so binds to the ROCm 7.0 runtime torch bundles, whose launch path serialises host threads - four
+    # predictor contexts then reach 18.8 images/s instead of 26.3 on the system's ROCm 7.2 runtime; tools/sn_images_in_flight.py, profiles/r05_clips_in_flight.txt)
     from unigeo_amd.stablenormal import StableNormalPredictorHIP
     H = W = 576
     pred = StableNormalPredictorHIP.from_random(seed=7, workspace_bytes=24 << 30)
+    # every context is created BEFORE the first launch of any of them: streams created after another context has been running end up sharing its hardware
+    # queues (4 images in flight: 18.7 images/s instead of 26.5; tools/sn_images_in_flight.py UG_SN_LATE)
+    nfl = max(1, a.in_flight if a.in_flight != 3 else 4)
+    extra = [StableNormalPredictorHIP.from_random(seed=7, workspace_bytes=8 << 30) for _ in range(nfl - 1)]
     rng = np.random.default_rng(0)
     yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
     img = np.stack([127.5 + 100 * np.sin(xx / 41.0 + c) * np.cos(yy / 29.0) for c in range(3)], -1)
+    x1 = (np.clip(img[None], 0, 255).astype(np.uint8).astype(np.float32) / 255.0)
+    for p_ in [pred] + extra:                  # ... and every context is used once before any of them is timed
+        p_.predict_batch(x1); p_.predict_batch(x1)
 
     def rate(B, n, warm):
         x = (np.clip(img[None] + rng.normal(0, 8, (B, H, W, 3)), 0, 255).astype(np.uint8).astype(np.float32) / 255.0)
@@ -250,6 +271,15 @@ def bench_stablenormal(a):
             pred.predict_batch(x)
         return n * B / (time.perf_counter() - t0), (time.perf_counter() - t0) / n * 1e3
     v1, ms1 = rate(1, a.steps, a.warmup)
+    # round 5: independent images in flight (the reference calls the predictor once per frame, model/stablenormal.py:39; frames are independent): a batch-1 image's
+    # launches have 81 - 5184 rows and leave most of the chip idle - further predictor contexts on their own streams / host threads run there
+    v_fl = None
+    if nfl > 1:
+        v_fl = sn_images_in_flight([pred] + extra, x1, max(2, a.steps))
+        if os.environ.get("UG_BENCH_DEBUG"):
+            print("[debug] hip runtimes mapped:", sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l}), "torch" in sys.modules, file=sys.stderr)
+        for p_ in extra:
+            p_.engine.close()
     v8, _ = rate(8, max(1, a.steps // 2), 1)
     # the reference's own use (configs/stablenormal_scannetpp.yaml): 25-frame clips at 384x512 - here one batch per clip
     x25 = np.clip(rng.uniform(0, 255, (25, 384, 512, 3)), 0, 255).astype(np.uint8).astype(np.float32) / 255.0
@@ -264,12 +294,14 @@ def bench_stablenormal(a):
     g_ms, g_fl = sum(v["ms"] for v in gem.values()), sum(v["flops"] for v in gem.values())
     calls = sum(v["calls"] for v in gem.values())
     ach = g_fl / (g_ms * 1e-3) / 1e12
-    res = {"metric": "images/sec (StableNormal, 576x576, YOSO + 10-step DINO-guided refinement)", "value": round(v1, 3), "unit": "frames/s",
-           "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms1, 2), "higher_is_better": True, "scaling": "weak",
+    res = {"metric": "images/sec (StableNormal, 576x576, YOSO + 10-step DINO-guided refinement)", "value": round(v_fl if v_fl else v1, 3), "unit": "frames/s",
+           "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 / v_fl if v_fl else ms1, 2), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "fp16", "data": "synthetic (seeded images, seeded random weights of the restated architecture, seeded prompt embedding)",
-           "config": {"workload": "StableNormal single 576x576 image per call (BASELINE configs[3]): SD VAE encode + ControlNet/UNet one-step estimate + "
+           "config": {"workload": f"StableNormal single 576x576 image per call (BASELINE configs[3]), {nfl} independent images in flight ({nfl} predictor contexts / host threads; "
+                                  "value_one_image_at_a_time = one context): SD VAE encode + ControlNet/UNet one-step estimate + "
                                   "DINOv2 ViT-L/14 + ControlNet + 10 x UNet DDIM refinement + VAE decode + normalisation; host<->device copies inside the call",
                       "batch": 1, "height": H, "width": W, "refine_steps": 10},
+           "value_one_image_at_a_time": round(v1, 3), "images_in_flight": nfl,
            "value_batch8": round(v8, 3), "value_clip25_384x512": round(v25, 3),
            "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS_F16, 4),
                         "traffic": None, "kernel": "gemm_kernel family (batch-1 image: M = 5184 / 1296 / 324 / 81 rows per level - launch- and weight-bandwidth-bound)",
@@ -620,6 +652,14 @@ def main():
                 for _ in range(5):
                     pred.predict_batch(img)
                 res["value_stablenormal_576_b1"] = round(5.0 / (time.perf_counter() - t1), 3)
+                try:    # four images in flight (four predictor contexts / host threads) in a process of its own: this one has torch loaded, i.e. runs on the ROCm
+                        # runtime torch bundles, whose launch path serialises host threads (18.8 instead of 26.3 images/s; bench_stablenormal)
+                    import re, subprocess
+                    o = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sn_images_in_flight.py"), "4", "5"], capture_output=True, text=True, timeout=600).stdout
+                    m = re.search(r"4 images in flight: ([0-9.]+) images/s", o)
+                    res["value_stablenormal_576_b1_4_in_flight"] = float(m.group(1)) if m else None
+                except Exception as e:
+                    res["stablenormal_in_flight_note"] = f"failed: {e!r}"
                 pe = pred.engine
                 pe.profile_begin(); pred.predict_batch(img); pr = pe.profile_end()
                 gm = {k: v for k, v in pr.items() if k.startswith("gemm_")}
