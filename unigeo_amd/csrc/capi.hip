@@ -138,9 +138,11 @@ int ug_set_coscheduled(ug_ctx* x, int on) {
   return 0;
 }
 int ug_set_ln_fold(ug_ctx* x, int mode) {
-  if (!x) return -1;
-  x->c.ln_fold = mode < 0 ? 0 : (mode > 2 ? 2 : mode); x->c.lane_need.clear();
-  return 0;
+  UG_TRY(x, {
+    Ctx& c = x->c;
+    c.ln_fold = mode < 0 ? 0 : (mode > 2 ? 2 : mode); c.lane_need.clear();
+    if (c.ln_fold) fold_unet_layernorms(c);                        // the folded weight copies, once (needs ~15 % of the UNet's size in the persistent arena)
+  });
 }
 int ug_set_fp8_linears(ug_ctx* x, int on) {
   if (!x) return -1;

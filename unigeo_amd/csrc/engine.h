@@ -182,6 +182,7 @@ void* pinned(Ctx& c, int slot, size_t bytes);   // page-locked staging buffer of
 // ---- binding ----
 void upload_raw(Ctx& c, const std::string& name, int dtype, const std::vector<long>& shape, const void* host);
 void bind_unet(Ctx& c, const UNetCfg& cfg, const std::string& prefix);
+void fold_unet_layernorms(Ctx& c);   // LayerNorm-folded weight copies for Ctx::ln_fold > 0 (made on demand)
 void bind_vae(Ctx& c, const VAECfg& cfg, const std::string& prefix);
 void bind_clip(Ctx& c, const CLIPCfg& cfg, const std::string& prefix);
 void finish_binding(Ctx& c, const std::string& prefix);   // fail on unused tensors, free raw

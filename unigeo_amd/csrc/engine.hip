@@ -541,6 +541,19 @@ static void fold_ln(Ctx& c, Lin& l, const Norm& n) {
   launch_fold_ln_weights(l.w, l.b, n.g, n.b, wf, fs, fb, l.out, l.in, c.stream);
   l.wf = wf; l.fs = fs; l.fb = fb;
 }
+// The five LayerNorms of every transformer block pair folded into the projections that consume them (transformer_forward, Ctx::ln_fold): 27 C^2 fp16 weights per
+// pair, 0.67 GB for the full UNet - made when the folded path is first switched on, not at bind time (the default path never reads them).
+void fold_unet_layernorms(Ctx& c) {
+  if (!c.unet.bound) return;
+  auto fold = [&](Transformer& t) {
+    if (t.qkv1.wf || !t.qkv1.w) return;
+    fold_ln(c, t.qkv1, t.ln1); fold_ln(c, t.ff1, t.ln3); fold_ln(c, t.ffin1, t.ln_in); fold_ln(c, t.tqkv, t.tln1); fold_ln(c, t.tff1, t.tln3);
+  };
+  for (auto& d : c.unet.down) for (auto& t : d.attn) fold(t);
+  for (auto& u : c.unet.up) for (auto& t : u.attn) fold(t);
+  fold(c.unet.mid_attn);
+  UG_CHECK(hipStreamSynchronize(c.stream));
+}
 static inline int pad8(int x) { return (x + 7) & ~7; }
 // MX-fp8 copy of a bound linear layer's weight (rows are quantised independently along K, so fused / re-ordered rows stay valid)
 static void quant_lin(Ctx& c, Lin& l) {
@@ -691,8 +704,7 @@ static Transformer bind_transformer(Ctx& c, const std::string& p, int C, int hea
   const float mix = raw_scalar(c, p + ".time_mixer.mix_factor");
   t.alpha = 1.f / (1.f + expf(-mix));
   for (Lin* l : {&t.proj_in, &t.proj_out, &t.qkv1, &t.o1, &t.ff1, &t.ff2, &t.ffin1, &t.ffin2, &t.tqkv, &t.to1, &t.tff1, &t.tff2}) quant_lin(c, *l);
-  // the five LayerNorms of a block pair can run folded into the projections that consume them (transformer_forward, Ctx::ln_fold)
-  fold_ln(c, t.qkv1, t.ln1); fold_ln(c, t.ff1, t.ln3); fold_ln(c, t.ffin1, t.ln_in); fold_ln(c, t.tqkv, t.tln1); fold_ln(c, t.tff1, t.tln3);
+  // (the LayerNorm-folded copies of qkv1 / ff1 / ffin1 / tqkv / tff1 are made on demand: fold_unet_layernorms, called by ug_set_ln_fold)
   return t;
 }
 
