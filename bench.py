@@ -379,7 +379,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
 
     from unigeo_amd.pipeline import DepthCrafterPipelineHIP, make_noise
-    from unigeo_amd.shard import DeviceArray
+    from unigeo_amd.shard import DeviceArray, run_in_flight
     from unigeo_amd.synthetic import synthetic_clip
     from unigeo_amd.model.depthcrafter import DepthCrafter
 
@@ -409,7 +409,6 @@ def main():
         inputs.append((fr_j, nl_j, na_j, K_j))
     frames, nl, na, K = inputs[0]
 
-    import threading
     t_clip, t_gather = [], []                              # per-clip wall of this rank: the engine call / the all_gather (N > 1)
 
     def gather_depth(e):                                   # reassemble outputs: RCCL all_gather over xGMI (main thread only: collectives keep one order on every rank)
@@ -422,47 +421,14 @@ def main():
         t_gather.append((time.perf_counter() - t_b) * 1e3)
 
     def run_clips(n):
-        """n clips of this rank, clip i on context i % nctx, up to nctx in flight.  Every context has a host thread that runs its clips back to back; with
-        N > 1 the main thread gathers each finished clip's depth in clip order (the same order on every rank) before that context starts its next clip."""
-        if nctx == 1:
-            for _ in range(n):
-                t_a = time.perf_counter()
-                eng.run(a.denoise_steps, 8, with_normals=False)   # returns after its own stream sync
-                t_clip.append((time.perf_counter() - t_a) * 1e3)
-                if multi:
-                    gather_depth(eng)
-            return
-        done = [threading.Event() for _ in range(n)]
-        gathered = [threading.Event() for _ in range(n)]
-        errs = []
-
-        def worker(j):
-            try:
-                for i in range(j, n, nctx):
-                    t_a = time.perf_counter()
-                    engs[j].run(a.denoise_steps, 8, with_normals=False)
-                    t_clip.append((time.perf_counter() - t_a) * 1e3)
-                    done[i].set()
-                    if multi:
-                        gathered[i].wait()
-            except Exception as ex:       # surface in the main thread
-                errs.append(ex)
-                for ev in done:
-                    ev.set()
-        th = [threading.Thread(target=worker, args=(j,)) for j in range(min(nctx, n))]
-        [t_.start() for t_ in th]
-        for i in range(n):
-            done[i].wait()
-            if errs:
-                break
-            if multi:
-                gather_depth(engs[i % nctx])
-                gathered[i].set()
-        for ev in gathered:
-            ev.set()
-        [t_.join() for t_ in th]
-        if errs:
-            raise errs[0]
+        """n clips of this rank, clip i on context i % nctx, up to nctx in flight (unigeo_amd.shard.run_in_flight): every context has a host thread that runs its
+        clips back to back; with N > 1 the main thread gathers each finished clip's depth in clip order (the same order on every rank) before that context
+        starts its next clip."""
+        def run_one(i, j):
+            t_a = time.perf_counter()
+            engs[j].run(a.denoise_steps, 8, with_normals=False)    # returns after its own stream sync
+            t_clip.append((time.perf_counter() - t_a) * 1e3)
+        run_in_flight(n, nctx, run_one, (lambda i, j: gather_depth(engs[j])) if multi else None)
 
     if a.warmup > 0:
         run_clips(max(a.warmup, nctx) if nctx > 1 else a.warmup)     # every context warm (first-launch attribute calls, clocks)

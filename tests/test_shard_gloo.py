@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from unigeo_amd.shard import clips_for_rank, rounds, run_sharded
+from unigeo_amd.shard import clips_for_rank, rounds, run_in_flight, run_sharded
 
 
 def _free_port():
@@ -81,6 +81,53 @@ def test_sharded_run_world8_ragged_tail():
     slices = [tuple(w) for w, _ in pins.values() if w is not None]
     if len(slices) == world and len(set(c for s_ in slices for c in s_)) >= world:
         assert len(set(slices)) == world                                    # distinct slices when the host has >= world cores
+
+
+def _inflight_worker(rank, world, port, n, nctx, q):
+    """bench.py's per-rank protocol with several clips in flight: contexts = host threads with their own output buffer; a clip's output is all_gathered from the
+    main thread, in clip order, before its context starts the next clip (which overwrites the buffer)."""
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bufs = [torch.zeros(4) for _ in range(nctx)]          # one "depth buffer" per context, overwritten by every run
+    rng = np.random.default_rng(rank)
+    delay = rng.uniform(0.0, 0.02, n)                     # clips finish out of order across contexts, differently on every rank
+    got, order = [], []
+
+    def run_clip(i, j):
+        time.sleep(float(delay[i]))
+        bufs[j].fill_(1000.0 * rank + i)
+
+    def after_clip(i, j):
+        order.append(i)
+        out = [torch.empty(4) for _ in range(world)]
+        dist.all_gather(out, bufs[j])
+        got.append([float(o[0]) for o in out])
+    run_in_flight(n, nctx, run_clip, after_clip)
+    q.put((rank, order, got))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,nctx", [(7, 3), (4, 2), (3, 1), (2, 3)])
+def test_clips_in_flight_keep_one_collective_order_world2(n, nctx):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_inflight_worker, args=(r, world, port, n, nctx, q)) for r in range(world)]
+    [p.start() for p in ps]
+    out = [q.get(timeout=120) for _ in range(world)]
+    [p.join(60) for p in ps]
+    for rank, order, got in out:
+        assert order == list(range(n))                                             # collectives in clip order on every rank
+        assert got == [[1000.0 * r + i for r in range(world)] for i in range(n)]   # clip i's gather saw clip i's output of every rank (no buffer overwritten early)
+
+
+def test_in_flight_runner_propagates_worker_errors():
+    def run_clip(i, j):
+        if i == 2:
+            raise ValueError("clip 2 failed")
+    with pytest.raises(ValueError):
+        run_in_flight(5, 2, run_clip, lambda i, j: None)
 
 
 def test_affinity_plan_physical_cores_per_numa_node():

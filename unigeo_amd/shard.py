@@ -52,6 +52,57 @@ def run_sharded(n_clips, rank, world, dist, run_clip, make_dummy):
     return results
 
 
+def run_in_flight(n, nctx, run_clip, after_clip=None):
+    """Several clips in flight on ONE GPU (round 5): clip ``i`` of this rank runs on context ``i % nctx``, every context on its own host thread
+    (``run_clip(i, i % nctx)`` blocks until that clip is done - the engine call releases the GIL).  ``after_clip(i, i % nctx)`` is called on the CALLING thread,
+    in clip order 0, 1, 2, ... - the place for the collective that reassembles a clip's output: every rank issues its collectives in the same order, from one
+    thread - and context ``i % nctx`` does not start its next clip before ``after_clip(i, ...)`` has returned (the next run overwrites the context's outputs).
+    Exceptions of a worker are re-raised here.  ``nctx == 1`` degenerates to the serial loop."""
+    import threading
+    nctx = max(1, min(nctx, n))
+    if nctx == 1:
+        for i in range(n):
+            run_clip(i, 0)
+            if after_clip:
+                after_clip(i, 0)
+        return
+    done = [threading.Event() for _ in range(n)]
+    released = [threading.Event() for _ in range(n)]
+    errs = []
+
+    def worker(j):
+        try:
+            for i in range(j, n, nctx):
+                run_clip(i, j)
+                done[i].set()
+                if after_clip:
+                    released[i].wait()
+                if errs:
+                    return
+        except Exception as ex:       # surface on the calling thread
+            errs.append(ex)
+            for ev in done:
+                ev.set()
+    th = [threading.Thread(target=worker, args=(j,)) for j in range(nctx)]
+    [t.start() for t in th]
+    try:
+        for i in range(n):
+            done[i].wait()
+            if errs:
+                break
+            if after_clip:
+                after_clip(i, i % nctx)
+                released[i].set()
+    except Exception as ex:
+        errs.append(ex)
+    finally:
+        for ev in released:
+            ev.set()
+        [t.join() for t in th]
+    if errs:
+        raise errs[0]
+
+
 def _parse_cpulist(txt):
     out = []
     for part in txt.strip().split(","):
