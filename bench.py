@@ -385,13 +385,15 @@ def main():
 
     T, H, W = a.frames, a.height, a.width
     nctx = max(1, min(a.in_flight, a.steps)) if not a.fp8 else 1
+    from unigeo_amd import weights as Wt
+    cfgs = Wt.tiny_cfgs() if a.tiny else (Wt.UNetCfg(), Wt.VAECfg(), Wt.CLIPCfg())
+    # the seeded random weights of from_random(seed=42), generated once on the host and uploaded into every context (a full replica each, as on separate GPUs)
+    states = (Wt.random_state(Wt.unet_manifest(cfgs[0]), 42), Wt.random_state(Wt.vae_manifest(cfgs[1]), 43), Wt.random_state(Wt.clip_manifest(cfgs[2]), 44))
     pipes = []
     for j in range(nctx):
-        if a.tiny:
-            from unigeo_amd import weights as Wt
-            pipes.append(DepthCrafterPipelineHIP.from_random(seed=42, cfgs=Wt.tiny_cfgs(), device_id=local, workspace_bytes=3 << 30))
-        else:
-            pipes.append(DepthCrafterPipelineHIP.from_random(seed=42, device_id=local, workspace_bytes=(40 << 30) if j == 0 else (12 << 30)))
+        ws = (3 << 30) if a.tiny else ((40 << 30) if j == 0 else (12 << 30))
+        pipes.append(DepthCrafterPipelineHIP.from_state(*states, cfgs=cfgs, device_id=local, workspace_bytes=ws))
+    del states
     engs = [p_.engine for p_ in pipes]
     pipe, eng = pipes[0], engs[0]
     if a.fp8:
