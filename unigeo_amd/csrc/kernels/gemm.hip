@@ -874,6 +874,25 @@ __global__ __launch_bounds__((WMW * WNW + 4) * 64, 3) void gemm_ws_kernel(const 
     const f16* Bb = smem + cp_slot * STAGE + BM * BK + (wn * WTN + l15) * BK;
     if (++cp_slot == NST) cp_slot = 0;
     {
+      // (BN = 160: 80 accumulator + 72 fragment registers do not fit the 168 three waves per SIMD leave - 20 - 28 bytes of scratch in the K loop; one 32-deep slice
+      // of fragments at a time there, round 5)
+      constexpr bool SLICE = MT * NT * 4 + 2 * (MT + NT) * 4 > 150;
+      if constexpr (SLICE) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int ch = ((kk * 4 + g) ^ sw) * 8;
+          f16x8 a1[MT], b1[NT];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) b1[j] = *(const f16x8*)(Bb + j * 16 * BK + ch);
+#pragma unroll
+          for (int i = 0; i < MT; ++i) a1[i] = *(const f16x8*)(Ab + i * 16 * BK + ch);
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1[j], a1[i], acc[i][j], 0, 0, 0);
+        }
+      } else {
       f16x8 af[2][MT], bf[2][NT];
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -899,6 +918,7 @@ __global__ __launch_bounds__((WMW * WNW + 4) * 64, 3) void gemm_ws_kernel(const 
       }
       __builtin_amdgcn_sched_group_barrier(0x008, Q - R * (Q / R), 0);
       __builtin_amdgcn_sched_group_barrier(0x008, Q, 0);
+      }
     }
     UG_STAMP(1);
     if (++cp_ks == nk) {
