@@ -253,7 +253,7 @@ def bench_stablenormal(a):
     pred = StableNormalPredictorHIP.from_random(seed=7, workspace_bytes=24 << 30)
     # every context is created BEFORE the first launch of any of them: streams created after another context has been running end up sharing its hardware
     # queues (4 images in flight: 18.7 images/s instead of 26.5; tools/sn_images_in_flight.py UG_SN_LATE)
-    nfl = max(1, a.in_flight if a.in_flight != 3 else 4)
+    nfl = max(1, a.sn_in_flight)
     extra = [StableNormalPredictorHIP.from_random(seed=7, workspace_bytes=8 << 30) for _ in range(nfl - 1)]
     rng = np.random.default_rng(0)
     yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
@@ -294,14 +294,15 @@ def bench_stablenormal(a):
     g_ms, g_fl = sum(v["ms"] for v in gem.values()), sum(v["flops"] for v in gem.values())
     calls = sum(v["calls"] for v in gem.values())
     ach = g_fl / (g_ms * 1e-3) / 1e12
-    res = {"metric": "images/sec (StableNormal, 576x576, YOSO + 10-step DINO-guided refinement)", "value": round(v_fl if v_fl else v1, 3), "unit": "frames/s",
-           "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 / v_fl if v_fl else ms1, 2), "higher_is_better": True, "scaling": "weak",
+    res = {"metric": "images/sec (StableNormal, 576x576, YOSO + 10-step DINO-guided refinement)", "value": round(v1, 3), "unit": "frames/s",
+           "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms1, 2), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "fp16", "data": "synthetic (seeded images, seeded random weights of the restated architecture, seeded prompt embedding)",
-           "config": {"workload": f"StableNormal single 576x576 image per call (BASELINE configs[3]), {nfl} independent images in flight ({nfl} predictor contexts / host threads; "
-                                  "value_one_image_at_a_time = one context): SD VAE encode + ControlNet/UNet one-step estimate + "
+           "config": {"workload": "StableNormal single 576x576 image per call, one call at a time (BASELINE configs[3]; reference model/stablenormal.py:39): "
+                                  "SD VAE encode + ControlNet/UNet one-step estimate + "
                                   "DINOv2 ViT-L/14 + ControlNet + 10 x UNet DDIM refinement + VAE decode + normalisation; host<->device copies inside the call",
                       "batch": 1, "height": H, "width": W, "refine_steps": 10},
-           "value_one_image_at_a_time": round(v1, 3), "images_in_flight": nfl,
+           "value_one_image_at_a_time": round(v1, 3), "value_images_in_flight": round(v_fl, 3) if v_fl else None, "images_in_flight": nfl,
+           "images_in_flight_note": f"SIDE rate: {nfl} independent images in flight ({nfl} predictor contexts / host threads, full weight replica each)",
            "value_batch8": round(v8, 3), "value_clip25_384x512": round(v25, 3),
            "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS_F16, 4),
                         "traffic": None, "kernel": "gemm_kernel family (batch-1 image: M = 5184 / 1296 / 324 / 81 rows per level - launch- and weight-bandwidth-bound)",
@@ -343,12 +344,16 @@ def main():
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "config0", "sample"],
                     help="config0 = BASELINE configs[0] as stated (25 frames 384x512, 2 Euler steps on the host cores: ~3-4 min on 32 threads); "
                          "sample = a 3-frame 192x256 clip (~10 s) extrapolated by algorithmic work; auto = config0 with >= 16 host cores")
-    ap.add_argument("--in-flight", type=int, default=3,
-                    help="independent clips in flight per GPU (round 5): that many engine contexts, each with its own weights replica, workspace, HIP stream and "
-                         "host thread; clip i of a rank runs on context i %% in_flight.  Clips are independent samples (reference eval.py:33-56), so this is the "
-                         "same sharding as over GPUs, one level down: a second clip fills the CUs that one clip's tile tails and under-filled launches leave idle "
-                         "(2 / 3 / 4 in flight with the co-scheduled heuristics: +12 / +15 / +15 %% aggregate, tools/two_clips_in_flight.py).  1 = one clip at a time (also always "
-                         "reported as value_one_clip_at_a_time)")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="independent clips in flight per GPU INSIDE THE TIMED REGION.  Default 1: `value` / `ms_per_step` are SURVEY 8(d)'s quantity - one clip per "
+                         "ug_dc_run call, one call at a time, as the reference harness drives the plugin (eval.py:33-39).  N > 1 = that many engine contexts (own weights "
+                         "replica, workspace, HIP stream, host thread; clip i on context i %% N) - the throughput mode for BASELINE configs[2]; the line then says so in "
+                         "config.workload and carries value_one_clip_at_a_time beside it")
+    ap.add_argument("--side-in-flight", type=int, default=3,
+                    help="clips in flight for the SIDE rate value_clips_in_flight, measured after the timed region on one GPU (0 / 1 = skip).  Clips are independent samples "
+                         "(reference eval.py:33-56): a second clip fills the CUs that one clip's tile tails and under-filled launches leave idle "
+                         "(tools/two_clips_in_flight.py)")
+    ap.add_argument("--sn-in-flight", type=int, default=4, help="--workload stablenormal: images in flight for value_images_in_flight (1 = skip)")
     ap.add_argument("--lanes", type=int, default=1, help="independent chunks (VAE encode / decode chunks, CLIP) in flight on separate HIP streams; 1 = serial")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the with-normals / N=5 / fp16-encoder / fp8 side rates (rocprofv3 runs)")
@@ -384,13 +389,15 @@ def main():
     from unigeo_amd.model.depthcrafter import DepthCrafter
 
     T, H, W = a.frames, a.height, a.width
-    nctx = max(1, min(a.in_flight, a.steps)) if not a.fp8 else 1
+    nctx = max(1, min(a.in_flight, a.steps)) if not a.fp8 else 1                      # contexts inside the timed region
+    n_side = a.side_in_flight if (world == 1 and not a.force_dist and not a.no_extras and not a.fp8 and a.side_in_flight > 1 and nctx == 1) else 0
+    nall = max(nctx, n_side)           # every context exists (and has run) BEFORE the timed region: streams created behind a busy context share its hardware queues
     from unigeo_amd import weights as Wt
     cfgs = Wt.tiny_cfgs() if a.tiny else (Wt.UNetCfg(), Wt.VAECfg(), Wt.CLIPCfg())
     # the seeded random weights of from_random(seed=42), generated once on the host and uploaded into every context (a full replica each, as on separate GPUs)
     states = (Wt.random_state(Wt.unet_manifest(cfgs[0]), 42), Wt.random_state(Wt.vae_manifest(cfgs[1]), 43), Wt.random_state(Wt.clip_manifest(cfgs[2]), 44))
     pipes = []
-    for j in range(nctx):
+    for j in range(nall):
         ws = (3 << 30) if a.tiny else ((40 << 30) if j == 0 else (12 << 30))
         pipes.append(DepthCrafterPipelineHIP.from_state(*states, cfgs=cfgs, device_id=local, workspace_bytes=ws))
     del states
@@ -403,9 +410,9 @@ def main():
         e.set_concurrency(a.lanes)
         if nctx > 1:
             e.set_coscheduled(True)                       # the contexts share the GPU during the timed clips
-        clip_j = synthetic_clip(T, H, W, seed=1234 + rank * nctx + j)
+        clip_j = synthetic_clip(T, H, W, seed=1234 + rank * nall + j)
         fr_j = DepthCrafter.prepare_input(None, clip_j)
-        nl_j, na_j = make_noise(T, H, W, seed=rank * nctx + j)
+        nl_j, na_j = make_noise(T, H, W, seed=rank * nall + j)
         K_j = np.stack(clip_j["intrinsics"], 0)
         e.set_inputs(fr_j, nl_j, na_j, K_j)               # inputs resident in HBM before the timed region
         inputs.append((fr_j, nl_j, na_j, K_j))
@@ -422,16 +429,20 @@ def main():
         torch.cuda.current_stream().synchronize()          # the context's next run overwrites its depth buffer
         t_gather.append((time.perf_counter() - t_b) * 1e3)
 
-    def run_clips(n):
-        """n clips of this rank, clip i on context i % nctx, up to nctx in flight (unigeo_amd.shard.run_in_flight): every context has a host thread that runs its
-        clips back to back; with N > 1 the main thread gathers each finished clip's depth in clip order (the same order on every rank) before that context
-        starts its next clip."""
+    def run_clips(n, nc=None):
+        """n clips of this rank, clip i on context i % nc, up to nc in flight (unigeo_amd.shard.run_in_flight; nc = 1: the plain serial loop of the reference
+        harness): every context has a host thread that runs its clips back to back; with N > 1 the main thread gathers each finished clip's depth in clip order
+        (the same order on every rank) before that context starts its next clip."""
+        nc = nctx if nc is None else nc
+
         def run_one(i, j):
             t_a = time.perf_counter()
             engs[j].run(a.denoise_steps, 8, with_normals=False)    # returns after its own stream sync
             t_clip.append((time.perf_counter() - t_a) * 1e3)
-        run_in_flight(n, nctx, run_one, (lambda i, j: gather_depth(engs[j])) if multi else None)
+        run_in_flight(n, nc, run_one, (lambda i, j: gather_depth(engs[j])) if multi else None)
 
+    if nall > nctx:
+        run_clips(nall, nall)                                        # the side-rate contexts run once before anything is timed (see nall above)
     if a.warmup > 0:
         run_clips(max(a.warmup, nctx) if nctx > 1 else a.warmup)     # every context warm (first-launch attribute calls, clocks)
     t_clip.clear(); t_gather.clear()
@@ -466,10 +477,19 @@ def main():
         for _ in range(3):
             eng.run(a.denoise_steps, 8, with_normals=False)
         value_one = 3 * T / (time.perf_counter() - t1)
+    value_side = None
+    if n_side > 1 and rank == 0:                            # the throughput mode as a SIDE rate: n_side co-scheduled contexts, clips back to back on each
+        for e in engs[:n_side]:
+            e.set_coscheduled(True)
+        n_fl = max(2 * n_side, min(a.steps, 4 * n_side))
+        run_clips(n_side, n_side)
+        t1 = time.perf_counter()
+        run_clips(n_fl, n_side)
+        value_side = n_fl * T / (time.perf_counter() - t1)
+    t_clip_timed = list(t_clip[:a.steps])
     for e in engs[1:]:                                      # the side rates and probes below use context 0 alone
         e.close()
-    if nctx > 1:
-        eng.set_coscheduled(False)
+    eng.set_coscheduled(False)
 
     if rank == 0:
         ms = dt / a.steps * 1000.0
@@ -492,8 +512,16 @@ def main():
                                           f"{nctx} x ms_per_step x 0.9); value_one_clip_at_a_time = the same binary with one clip in flight")
             if value_one is not None:
                 res["value_one_clip_at_a_time"] = round(value_one, 3)
+        else:
+            res["config"]["workload"] += "; one clip per ug_dc_run call, one call at a time (SURVEY 8d; reference eval.py:33-39)"
+            res["value_one_clip_at_a_time"] = round(value, 3) if world == 1 else None      # the same number: kept for round-over-round comparison (r5 reported it beside an in-flight `value`)
+        if value_side is not None:
+            res["value_clips_in_flight"] = round(value_side, 3)
+            res["clips_in_flight_note"] = (f"SIDE rate, not `value`: {n_side} independent clips in flight on this GPU ({n_side} co-scheduled engine contexts / HIP streams / host threads, "
+                                           "full weight replica each) - the throughput mode for a dataset of clips (BASELINE configs[2]; harness.evaluate(models=[...])); an unchanged "
+                                           "reference eval.py calls the plugin one clip at a time and gets `value`")
         res["per_rank_ms"] = {"columns": ["clip_mean", "clip_max", "gather_mean", "gather_max"],
-                              "ranks": per_rank if per_rank is not None else [[round(float(np.mean(t_clip)), 2), round(float(np.max(t_clip)), 2), 0.0, 0.0]],
+                              "ranks": per_rank if per_rank is not None else [[round(float(np.mean(t_clip_timed)), 2), round(float(np.max(t_clip_timed)), 2), 0.0, 0.0]],
                               "host_affinity": affinity}
         res["calibration"] = {**calibration_probe(eng, local), **smi.summary(),
                               "note": "probes run in this process right after the timed clips; sclk / power sampled at 20 Hz during them (None = SMI not readable in this container)"}
@@ -560,6 +588,25 @@ def main():
                                             ((frames.nbytes + nl.nbytes + na.nbytes) / 1e6, (T * H * W * 4 * 4) / 1e6))
             except Exception as e:
                 res["host_to_host_note"] = f"host-to-host side rate failed: {e!r}"
+            # What a maintainer of the reference calls: model.forward(data) of the plugin class (reference eval.py:39 -> model/depthcrafter.py:73-99) in a process
+            # that imported torch first (this one did): prepare_input, seeded noise drawn on the host (torch CPU generator), upload, ug_dc_run WITH the normals of
+            # prepare_output, download of frames / depth / normals, CPU torch tensors out.
+            try:
+                plug = DepthCrafter.__new__(DepthCrafter)
+                plug.pipeline, plug.num_inference_steps, plug.seed, plug._calls, plug.device = pipe, a.denoise_steps, 0, 0, f"hip:{local}"
+                data = synthetic_clip(T, H, W, seed=1234)
+                out = plug.forward(data)
+                assert tuple(out["pred_depths"].shape) == (T, H, W) and tuple(out["pred_normals"].shape) == (T, H, W, 3)
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    plug.forward(data)
+                res["value_plugin_forward"] = round(2 * T / (time.perf_counter() - t1), 3)
+                t1 = time.perf_counter(); make_noise(T, H, W, seed=1); t_noise = time.perf_counter() - t1
+                res["plugin_forward_note"] = ("frames/s of DepthCrafter.forward(data) as reference eval.py:39 calls it, torch imported first: prepare_input + host noise draw "
+                                              f"({t_noise * 1e3:.0f} ms per clip on this host) + upload + ug_dc_run incl. normals + download + torch tensors")
+                eng.set_inputs(frames, nl, na, K)
+            except Exception as e:
+                res["plugin_forward_note"] = f"plugin forward side rate failed: {e!r}"
         if full and not a.no_profile and not a.no_extras:
             # also report the rate with prepare_output's normals inside the call, the reference-as-shipped N = 5 rate
             # (model/depthcrafter.py:86) and the cost of the reference-faithful float32 VAE encoder vs the fp16-storage one

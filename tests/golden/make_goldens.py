@@ -132,3 +132,16 @@ G["g7_normals"] = torch.stack([torch.from_numpy(x).float() for x in pn_], dim=0)
 
 np.savez_compressed(os.path.join(OUT, "reference_goldens.npz"), **G)
 print("wrote", os.path.join(OUT, "reference_goldens.npz"), {k: v.shape for k, v in G.items()})
+
+# G3 at full frame size ("48x64 and one 384x512 frame"; round 6): the reference's own prepare_output on ONE 384x512 frame - the depth and intrinsics
+# of tests/test_pipeline_gpu.py::test_normals_kernel_vs_reference_golden_full_frame.  Its own file (2 MB), so that the fixtures above keep their bytes.
+H, W = 384, 512
+yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+d_full = (3.0 + np.sin(xx / 50.0) * np.cos(yy / 37.0) + 0.003 * yy).astype(np.float32)
+f_ = 500.0 * (W / 640.0)
+K_full = np.array([[f_, 0, W / 2.0], [0, f_, H / 2.0], [0, 0, 1]], np.float32)          # = unigeo_amd.synthetic.synthetic_clip's intrinsics
+torch.manual_seed(0)
+out = wrapper.prepare_output([d_full.copy()], {"intrinsics": [K_full]})
+np.savez_compressed(os.path.join(OUT, "reference_g3_fullframe.npz"), g3f_depth=d_full, g3f_K=K_full,
+                    g3f_pred_depths=out["pred_depths"].numpy(), g3f_pred_normals=out["pred_normals"].numpy())
+print("wrote reference_g3_fullframe.npz", out["pred_normals"].shape)

@@ -182,3 +182,48 @@ def test_headline_workload_against_an_fp16_run_of_the_oracle(run):
     assert r_h32 < 1.5 * r_1632 + 2e-3, (r_h32, r_1632)
     # the metrics of the fp16 run of the oracle equal the fp32 oracle's (and hence HIP's, test_frames_depth_and_metrics) to 5 / 4 significant figures
     assert g16["metrics"][0] == pytest.approx(g32["metrics"][0], rel=1e-5) and g16["metrics"][2] == pytest.approx(g32["metrics"][2], rel=1e-4)
+
+
+def test_three_clips_in_flight_match_the_solo_run_and_the_golden():
+    """VERDICT r5 missing 2: the throughput mode bench.py reports as value_clips_in_flight - three engine contexts (own weight replica, workspace, stream, host
+    thread) running CONCURRENTLY on one GPU with the co-scheduled heuristics - was only ever covered on a single context.  Here all three run the golden clip at
+    the same time (unigeo_amd.shard.run_in_flight, as bench.py and harness.evaluate(models=[...]) drive it), twice: every context's frames / depth must be
+    bit-identical to a solo co-scheduled run (contexts share nothing but the chip) and inside the bounds of the oracle fixture.
+    Reference contract it stands in for: /root/reference/eval.py:33-39 (one clip at a time)."""
+    from unigeo_amd import weights as Wt
+    from unigeo_amd.model.depthcrafter import DepthCrafter
+    from unigeo_amd.pipeline import DepthCrafterPipelineHIP, make_noise
+    from unigeo_amd.shard import run_in_flight
+    from unigeo_amd.synthetic import synthetic_clip
+    g = dict(np.load(GOLD))
+    T, H, W, steps = (int(x) for x in g["geometry"])
+    cfgs = (Wt.UNetCfg(), Wt.VAECfg(), Wt.CLIPCfg())
+    states = (Wt.random_state(Wt.unet_manifest(cfgs[0]), 42), Wt.random_state(Wt.vae_manifest(cfgs[1]), 43), Wt.random_state(Wt.clip_manifest(cfgs[2]), 44))   # = from_random(seed=42)
+    pipes = [DepthCrafterPipelineHIP.from_state(*states, cfgs=cfgs, workspace_bytes=(40 << 30) if j == 0 else (12 << 30)) for j in range(3)]
+    del states
+    engs = [p.engine for p in pipes]
+    try:
+        sample = synthetic_clip(T, H, W, seed=1234)
+        frames = DepthCrafter.prepare_input(None, sample)
+        nl, na = make_noise(T, H, W, seed=0)
+        K = np.stack(sample["intrinsics"], 0)
+        for e in engs:
+            e.set_coscheduled(True)
+            e.set_inputs(frames, nl, na, K)
+        engs[0].run(steps, 8, with_normals=False)
+        fr_solo, d_solo, _ = engs[0].get_outputs(frames=True, depth=True, normals=False)
+        order = []
+        for rep in range(2):
+            run_in_flight(3, 3, lambda i, j: (engs[j].run(steps, 8, with_normals=False), order.append(j)))
+            for j, e in enumerate(engs):
+                fr, d, _ = e.get_outputs(frames=True, depth=True, normals=False)
+                assert np.array_equal(fr, fr_solo) and np.array_equal(d, d_solo), f"context {j}, repetition {rep}: a clip that shared the GPU differs from the solo run"
+        assert sorted(order) == [0, 0, 1, 1, 2, 2]
+        e_sub = float(np.abs(fr_solo[:, ::4, ::4] - g["frames_sub"].astype(np.float32)).max())
+        e_depth = float((np.abs(d_solo[:, ::4, ::4] - g["depth_sub"]) / g["depth_sub"]).max())
+        report("fullsize.in_flight3.frames_abs_err_subsampled", e_sub); report("fullsize.in_flight3.depth_rel_err_subsampled", e_depth)
+        rng_ = float(g["frames_max"]) - float(g["frames_min"])
+        assert e_sub < 7e-3 + 5e-4 and e_depth < min(3e-2, 10.0 * 2.0 * (7e-3 + 5e-4) / rng_), (e_sub, e_depth)
+    finally:
+        for e in engs:
+            e.close()

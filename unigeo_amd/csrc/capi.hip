@@ -127,7 +127,7 @@ int ug_dc_run_windows(ug_ctx* x, int steps, int chunk, int with_normals, int win
 }
 int ug_set_ff_fused(ug_ctx* x, int on) {
   if (!x) return -1;
-  x->c.ff_fused = on & 3; x->c.lane_need.clear();   // bit 0: fused feed-forward kernel, bit 1: its pre-LayerNorm inside the kernel  (a feature toggle changes the transient memory a lane task needs) LayerNorm -> Q|K|V projection
+  x->c.ff_fused = on & 3; x->c.lane_need.clear();   // bit 0: fused feed-forward kernel, bit 1: its pre-LayerNorm inside the kernel (a feature toggle changes the transient memory a lane task needs)
   return 0;
 }
 int ug_set_coscheduled(ug_ctx* x, int on) {
@@ -871,6 +871,7 @@ int ug_op_proj_ln_linear(ug_ctx* x, const float* A, int M, int K0, const float* 
         int want = 0;
         if (gemm_epilogue_ext_ok(q, 1, &want) && want <= cap) {
           q.row_part = part;
+          UG_CHECK(hipMemsetAsync(part, 0x7f, (size_t)M * cap * sizeof(float2), c.stream));   // poison (3.4e38): a slot the epilogue is counted for but never writes shows in y
           if (dvec) { q.bias2 = dvec; q.bias2_rows = rows_per_vec >= M ? 0 : rows_per_vec; }
           launch_gemm(q, 1, c.stream, nullptr, &slots);
           s_final = s1; have = true;
@@ -950,7 +951,10 @@ int ug_bench_mfma_peak(ug_ctx* x, int iters, float* tflops_out) {
 }
 int ug_tune_force(ug_ctx* x, int cfg, int split) {
   if (!x) return -1;
-  if (cfg <= -100) x->c.tune.knobs = -cfg - 100;             // knob mask: ug_tune_force(ctx, -100 - knobs, 0)
+  if (cfg <= -100) {                                         // knob mask: ug_tune_force(ctx, -100 - knobs, 0)
+    x->c.tune.knobs = (-cfg - 100) & ~4194304;
+    if (x->c.cosched) x->c.tune.knobs |= 4194304;            // the co-scheduled planner rule belongs to ug_set_coscheduled alone: a forced mask neither sets nor drops it
+  }
   else { x->c.tune.cfg = cfg; x->c.tune.split = split; }
   x->c.lane_need.clear();    // forced split-K / tile configs change the partial buffers a lane task needs
   return 0;

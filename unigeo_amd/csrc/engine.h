@@ -35,7 +35,7 @@ class Arena {
 };
 
 struct Lin { const f16* w = nullptr; const f16* b = nullptr; int in = 0, out = 0;
-             // LayerNorm folded in (round 5, fold_ln at bind time): wf = fp16(gamma o w), fs[n] = sum_k wf[n][k], fb[n] = b[n] + sum_k beta[k] w[n][k] (GemmP::ln_stat)
+             // LayerNorm folded in (round 5, fold_ln at bind time): CENTRED folded weights wf = fp16(gamma o w - rowmean(gamma o w)) so that x wf^T = (x - mean)(gamma o w)^T, fb[n] = b[n] + sum_k beta[k] w[n][k]; the epilogue computes rstd[m] acc + fb[n] - no mean term (fs is kept for the kernels' argument checks, never read) (GemmP::ln_stat)
              const f16* wf = nullptr; const float* fs = nullptr; const float* fb = nullptr;
              // optional MX-fp8 copy of the weight (kernels/mx8.hip): e4m3 bytes [out][in] + e8m0 block scales [in/128][ld_sw8] dwords
              const unsigned char* w8 = nullptr; const unsigned* sw8 = nullptr; long ld_sw8 = 0; };

@@ -312,7 +312,7 @@ static void linear(Ctx& c, const f16* A, long M, const Lin& l, f16* out, const E
   }
   p.A0 = A; p.C0 = (int)(lda ? lda : l.in); p.M = (int)M; p.N = l.out; p.K = l.in;
   p.W = l.w; p.ldw = l.in; p.bias = l.b; p.bias2 = e.bias2; p.bias2_rows = e.bias2_rows;
-  if (e.ln_stat) {   // A is the raw stream: LayerNorm(A) W^T + b = rstd (A Wf^T - mean fs) + fb in the epilogue
+  if (e.ln_stat) {   // A is the raw stream: LayerNorm(A) W^T + b = rstd (A Wf^T) + fb in the epilogue, Wf = the centred folded weights (engine.h: Lin::wf)
     UG_REQUIRE(l.wf && l.fs && l.fb, "linear: LayerNorm fold requested for a layer that was not folded at bind time");
     p.W = l.wf; p.bias = nullptr; p.ln_stat = e.ln_stat; p.ln_s = l.fs; p.ln_bias = l.fb;
   }
@@ -1097,8 +1097,7 @@ static f16* transformer_forward(Ctx& c, const Transformer& tr, const f16* x, int
   const size_t mk = c.ws.mark();
   f16* t1 = c.ws.get<f16>(M * C);
   groupnorm(c, x, C, nullptr, 0, T, HW, G, tr.gn, 0, 0, t1, in_stats);
-  f16* h0 = c.ws.get<f16>(M * C);
-  linear(c, t1, M, tr.proj_in, h0);
+  f16* h0 = c.ws.get<f16>(M * C);     // proj_in is launched below, once the fold decision of its consumer is known
   // fp8 linear path: the LayerNorms feeding a linear layer write MX-fp8 directly (no fp16 copy, no separate quantiser pass)
   const bool q8 = c.fp8_linears && !getenv("UG_NO_LNQ") && C % 128 == 0 && M >= 256 && tr.qkv1.w8 && tr.ff1.w8 && tr.ffin1.w8 && tr.tqkv.w8 && tr.tff1.w8;
   QAct qa; if (q8) qa = qact_alloc(c, M, C);

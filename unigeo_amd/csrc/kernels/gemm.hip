@@ -1445,7 +1445,9 @@ bool gemm_epilogue_ext_ok(const GemmP& p0, int batch, int* slots) {
   const bool pk = (cfg == 63 || cfg == 64) && gemm_can_bufa(p, 64, true);
   const bool ldr_fold = cfg == 35 && gemm_can_bufa(p, 64, true) && !p.row_part && p.bias2_rows <= 0;     // the 256 x 256 loader tile: the LayerNorm fold alone
   if (!(cfg == 3 || cfg == 0 || pk || ldr_fold)) return false;
-  if (slots) *slots = cdiv(p.N, bn) * wnw;
+  // slot index in tile_epilogue = global wave-column index (n0 / WTN + wn); a wave column entirely beyond N never writes its slot, so only the in-range
+  // ones count (N % 64 == 0 and WTN = bn / wnw in {32, 64} make the division exact) - k_rowstat_finalize sums every slot it is told about
+  if (slots) *slots = p.N / (bn / wnw);
   return true;
 }
 

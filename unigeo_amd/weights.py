@@ -596,6 +596,40 @@ def dino_manifest(cfg: DinoCfg = DinoCfg()) -> "OrderedDict[str, tuple]":
     return m
 
 
+def dinov2_hf_to_hub(state):
+    """A `transformers.Dinov2Model` state dict -> dinov2 hub naming (what dino_manifest lists): the fused `attn.qkv` is query | key | value stacked in that order.
+    Pinned against transformers by tests/test_oracle_structure.py::test_dinov2_oracle_matches_transformers."""
+    out = OrderedDict()
+    cat = lambda parts: np.concatenate([np.asarray(x) for x in parts], 0)
+    layers = sorted({int(k.split(".")[2]) for k in state if k.startswith("encoder.layer.")})
+    out["cls_token"] = state["embeddings.cls_token"]; out["pos_embed"] = state["embeddings.position_embeddings"]
+    out["patch_embed.proj.weight"] = state["embeddings.patch_embeddings.projection.weight"]
+    out["patch_embed.proj.bias"] = state["embeddings.patch_embeddings.projection.bias"]
+    for i in layers:
+        h, b = f"encoder.layer.{i}", f"blocks.{i}"
+        for wb in ("weight", "bias"):
+            out[f"{b}.norm1.{wb}"] = state[f"{h}.norm1.{wb}"]; out[f"{b}.norm2.{wb}"] = state[f"{h}.norm2.{wb}"]
+            out[f"{b}.attn.qkv.{wb}"] = cat([state[f"{h}.attention.attention.{n}.{wb}"] for n in ("query", "key", "value")])
+            out[f"{b}.attn.proj.{wb}"] = state[f"{h}.attention.output.dense.{wb}"]
+            out[f"{b}.mlp.fc1.{wb}"] = state[f"{h}.mlp.fc1.{wb}"]; out[f"{b}.mlp.fc2.{wb}"] = state[f"{h}.mlp.fc2.{wb}"]
+        out[f"{b}.ls1.gamma"] = state[f"{h}.layer_scale1.lambda1"]; out[f"{b}.ls2.gamma"] = state[f"{h}.layer_scale2.lambda1"]
+    out["norm.weight"] = state["layernorm.weight"]; out["norm.bias"] = state["layernorm.bias"]
+    return out
+
+
+def resample_dino_pos_embed(pe, g_dst: int):
+    """DINOv2 position table [1, 1 + g_src^2, D] -> [1, 1 + g_dst^2, D]: the class row kept, the patch grid resampled bicubically (align_corners False,
+    target SIZE given) - transformers' `Dinov2Embeddings.interpolate_pos_encoding` (pinned by test_dinov2_position_table_resampling_matches_transformers)."""
+    pe = np.asarray(pe, np.float32)
+    g_src = int(round((pe.shape[1] - 1) ** 0.5))
+    if g_src == g_dst:
+        return pe
+    import torch
+    grid = torch.from_numpy(pe[0, 1:]).reshape(1, g_src, g_src, -1).permute(0, 3, 1, 2)
+    grid = torch.nn.functional.interpolate(grid, size=(g_dst, g_dst), mode="bicubic", align_corners=False)
+    return np.concatenate([pe[:, :1], grid.permute(0, 2, 3, 1).reshape(1, g_dst * g_dst, -1).numpy()], 1)
+
+
 def load_stablenormal_pretrained(model_dir: str, cfgs=None):
     """Checkpoint directory -> ({component: state}, prompt_embeds [77,1024]).  Expected layout (diffusers-style, one sub-directory per
     component; S11): ``vae/``, ``unet_yoso/``, ``controlnet_yoso/``, ``unet/``, ``controlnet_dino/`` each with
@@ -610,14 +644,10 @@ def load_stablenormal_pretrained(model_dir: str, cfgs=None):
     for comp, m in man.items():
         st = load_safetensors(_first_existing(os.path.join(model_dir, comp), names))
         if comp == "dino":
+            if "embeddings.cls_token" in st:                      # a transformers Dinov2Model checkpoint instead of the hub's naming
+                st = dinov2_hf_to_hub(st)
             st = {k: v for k, v in st.items() if k != "mask_token"}
-            pe = st["pos_embed"]
-            g_src, g_dst = int(round((pe.shape[1] - 1) ** 0.5)), cfgs[2].image_size // cfgs[2].patch_size
-            if g_src != g_dst:
-                import torch
-                grid = torch.from_numpy(np.asarray(pe[0, 1:], np.float32)).reshape(1, g_src, g_src, -1).permute(0, 3, 1, 2)
-                grid = torch.nn.functional.interpolate(grid, size=(g_dst, g_dst), mode="bicubic", align_corners=False)
-                st["pos_embed"] = np.concatenate([np.asarray(pe[:, :1], np.float32), grid.permute(0, 2, 3, 1).reshape(1, g_dst * g_dst, -1).numpy()], 1)
+            st["pos_embed"] = resample_dino_pos_embed(st["pos_embed"], cfgs[2].image_size // cfgs[2].patch_size)
         check_against_manifest(st, m, f"StableNormal {comp}")
         states[comp] = st
     pe_file = os.path.join(model_dir, "prompt_embeds.npy")
