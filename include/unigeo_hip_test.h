@@ -21,14 +21,6 @@ int ug_set_ff_fused(ug_ctx* ctx, int on);   /* bit 0: fused feed-forward kernel,
  * mode 0: LayerNorm launch + two GEMMs, 1: LayerNorm launch + fused feed-forward, 2: all inside the fused kernel (product path at C <= 320). */
 int ug_op_ln_ff(ug_ctx* ctx, const float* X, int M, int C, const float* gamma, const float* beta, float eps, const float* addvec, int rows_per_vec,
                 const float* W1, const float* b1, const float* W2, const float* b2, float c0, float c1, int mode, float* out);
-/* LayerNorm folded into its consumer GEMM (round 5; the reference's BasicTransformerBlock norm1 / norm3 and TemporalBasicTransformerBlock norm_in / norm1 /
- * norm3 followed by to_q|k|v / ff.net.0.proj, inside the un-vendored UNet): 0 = LayerNorm launches (default), 1 = folded at M >= 4096, 2 = wherever the kernels can.
- * ug_op_proj_ln_linear evaluates  s = A Wp^T + bp (+ R) (+ vec[row / rows_per_vec]);  y = (GEGLU of) LayerNorm(s) W^T + bias  with mode 0 = three passes,
- * 1 = statistics-only launch + folded GEMM, 2 = row sums from the projection's epilogue + folded GEMM (W in diffusers order; slots_out: see capi.hip). */
-int ug_set_ln_fold(ug_ctx* ctx, int mode);
-int ug_op_proj_ln_linear(ug_ctx* ctx, const float* A, int M, int K0, const float* Wp, const float* bp, int C, const float* R, const float* vec, int rows_per_vec,
-                         const float* gamma, const float* beta, float eps, const float* W, const float* bias, int N, int geglu, int mode,
-                         float* s_out, float* y_out, int* slots_out);
 int ug_bench_flash(ug_ctx* ctx, int B, int H, int S, int variant, int iters, float* us_out);   /* flash-attention A/B on device-resident random data */
 int ug_bench_ff(ug_ctx* ctx, int M, int C, int fused, int iters, float* us_out);
 int ug_op_ff(ug_ctx* ctx, const float* X, int M, int C, const float* W1, const float* b1, const float* W2, const float* b2, const float* R1,

@@ -150,49 +150,6 @@ def test_layernorm(engine, C):
     assert_close(y, F.layer_norm(t(xs), (C,), t(gm), t(bt), 1e-5).numpy(), TOL, "layernorm with pre-add")
 
 
-@pytest.mark.parametrize("M,K0,C,N,geglu,rows_per_vec,want_slots", [
-    (19200, 640, 640, 1920, False, 768, 20),     # level 1: attention out-projection (+ per-frame cross-attention row) -> LayerNorm -> Q|K|V, 192 x 128 producer / consumer tiles: 5 column tiles x 4 wave columns
-    (4800, 1280, 1280, 10240, True, 192, 40),    # level 2: ... -> LayerNorm -> GEGLU projection (the 192 x 128 tile stands in for the 256 x 256 one)
-    (4800, 5120, 1280, 3840, False, 0, 20),      # level 2: feed-forward down-projection (K = 4C, 64-column wave tiles) -> LayerNorm -> temporal Q|K|V, no broadcast row
-    (9600, 320, 320, 2560, True, 4800, -320),    # narrow width on the tiled kernels (the clip's level 0 has its own fused forms; StableNormal-sized launches do not); 320 columns on 128-column tiles: the wave columns beyond N write no slot - slots = 320 / 32 or 320 / 64 by tile
-    (320, 64, 64, 192, False, 64, -1),           # the tiny configuration of the pipeline tests: few-row 128 x 64 tiles
-    (1000, 128, 128, 1024, True, 250, -1),       # ragged M, GEGLU on the 128 x 128 tile
-])
-def test_layernorm_folded_into_consumer_gemm(engine, M, K0, C, N, geglu, rows_per_vec, want_slots):
-    """Round 5: LayerNorm folded into the GEMM that consumes it -  y = LN(s) W^T + b = rstd (s Wc^T) + b'  with the CENTRED folded weights
-    Wc = fp16(gamma o W - rowmean(gamma o W)) (so s Wc^T = (s - mean)(gamma o W)^T: no mean term in the epilogue), the row
-    statistics either from the statistics-only LayerNorm launch (mode 1) or from the partial sums the producing projection's epilogue leaves (mode 2, which also
-    adds the per-frame broadcast row in that epilogue) - against fp32 torch on the fp16-rounded operands and against the three-pass form (mode 0)."""
-    rng = np.random.default_rng(M + N)
-    A = rnd(rng, M, K0)
-    Wp, bp = rnd(rng, C, K0, scale=K0 ** -0.5), rnd(rng, C, scale=0.1)
-    R = rnd(rng, M, C) + 0.25                                   # a residual stream with a non-zero mean
-    nv = (M + rows_per_vec - 1) // rows_per_vec if rows_per_vec else 0
-    vec = rnd(rng, nv, C, scale=0.5) if nv else None
-    gm, bt = h16(1.0 + 0.2 * rng.standard_normal(C)), h16(0.1 * rng.standard_normal(C))
-    W, b = rnd(rng, N, C, scale=C ** -0.5), rnd(rng, N, scale=0.1)
-    s_ref = t(A) @ t(Wp).T + t(bp) + t(R)
-    if vec is not None:
-        s_ref = s_ref + t(np.repeat(vec, rows_per_vec, 0)[:M])
-    got = {}
-    for mode in (0, 1, 2):
-        s, y, slots = engine.op_proj_ln_linear(A, Wp, bp, gm, bt, W, b, R=R, vec=vec, rows_per_vec=max(rows_per_vec, 1), geglu=geglu, mode=mode)
-        got[mode] = (s, y, slots)
-        assert_close(s, s_ref.numpy(), TOL, f"LN fold mode {mode}: the stream s ({M}x{C})")
-        # the reference LayerNorm acts on the STORED (fp16) stream, as the consumer reads it
-        yn = F.layer_norm(t(s), (C,), t(gm), t(bt), 1e-5) @ t(W).T + t(b)
-        if geglu:
-            h, g = yn.chunk(2, -1)
-            yn = h * F.gelu(g)
-        assert_close(y, yn.numpy(), TOL, f"LN fold mode {mode}: y ({M}x{N}{' GEGLU' if geglu else ''})")
-    if want_slots >= 0:
-        assert got[2][2] == want_slots, f"row-partial slots {got[2][2]}, expected {want_slots}"
-    elif want_slots < -1:       # only the wave columns inside N (= -want_slots) count: 32- or 64-column wave tiles
-        assert got[2][2] in (-want_slots // 32, -want_slots // 64), f"row-partial slots {got[2][2]} for N = {-want_slots}"
-    # modes 1 and 2 differ only in where (mean, rstd) come from and in one rounding of s (mode 2 adds the row before the store): same bound against each other
-    assert_close(got[2][1], got[1][1], 2 * TOL, "LN fold: epilogue row sums vs statistics launch")
-
-
 def attn_ref(qkv, B, S, H, d):
     q, k, v = t(qkv).reshape(B, S, 3, H, d).permute(2, 0, 3, 1, 4)
     w = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, -1)

@@ -73,25 +73,18 @@ def test_vae_decode(tiny, T):
     assert_abs(got, ref, 5e-3, f"tiny VAE decode T={T} (frames in [0,1])")
 
 
-@pytest.mark.parametrize("T,h,w,ln_fold", [(3, 8, 8, 1), (5, 8, 16, 1), (5, 8, 16, 2), (5, 8, 16, 0)])
-def test_unet_forward(tiny, T, h, w, ln_fold):
-    """ln_fold: 0 = LayerNorm launches (the default: the folded form measured +14 ms per clip), 1 = folded at M >= 4096 (at these sizes nowhere),
-    2 = folded wherever the kernels can (every transformer block of the tiny configuration: row sums from the producing projections' epilogues, per-frame rows
-    added there)."""
+@pytest.mark.parametrize("T,h,w", [(3, 8, 8), (5, 8, 16)])
+def test_unet_forward(tiny, T, h, w):
     rng = np.random.default_rng(3)
     u = tiny["cfgs"][0]
     x = h16(rng.standard_normal((T, u.in_channels, h, w)))
     emb = h16(rng.standard_normal((T, u.cross_attention_dim)))
     tstep = 0.25 * np.log(3.7)
-    try:
-        tiny["eng"].set_ln_fold(ln_fold)
-        got = tiny["eng"].unet_forward(x, tstep, emb)
-    finally:
-        tiny["eng"].set_ln_fold(0)
+    got = tiny["eng"].unet_forward(x, tstep, emb)
     with torch.no_grad():
         ref = tiny["unet"](torch.from_numpy(x)[None], torch.tensor(tstep), torch.from_numpy(emb)[None],
                            torch.tensor([[7.0, 127.0, 0.02]]))[0].numpy()
-    assert_close(got, ref, 4.5e-3, f"UNet forward (ln_fold {ln_fold})")
+    assert_close(got, ref, 4.5e-3, "UNet forward")
 
 
 def test_pipeline_end_to_end(tiny):
@@ -247,10 +240,6 @@ def test_full_architecture_unet_and_vae_decoder_small_clip():
                 ref16 = unet(torch.from_numpy(x)[None], torch.tensor(tstep), torch.from_numpy(emb)[None], torch.tensor([[7.0, 127.0, 0.02]]))[0].numpy()
         del unet
         assert_close(got, ref, 3.5e-3, "full-architecture UNet forward")
-        pipe.engine.set_ln_fold(2)           # round 5: every LayerNorm folded into its consumer GEMM wherever the kernels can (the clip's levels 1 / 2 run this way)
-        got_f = pipe.engine.unet_forward(x, tstep, emb)
-        pipe.engine.set_ln_fold(0)
-        assert_close(got_f, ref, 3.5e-3, "full-architecture UNet forward, LayerNorms folded into their consumers")
         report("full-architecture UNet: |fp16-storage oracle - fp32 oracle| / max", rel_err(ref16, ref))
         report("full-architecture UNet: |HIP - fp16-storage oracle| / max (the quantity north_star's 1e-3 bounds)", rel_err(got, ref16))
         z = h16(rng.standard_normal((2, 4, 8, 8)) * 2)

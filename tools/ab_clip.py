@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """In-process A/B of engine switches on the full-size clip (25 x 384 x 512, 25 steps): box-to-box spread is +-4 %, so variants are
-only ever compared inside one process.  usage: ab_clip.py epipre|lnfold|walk|rowmajor|ff_fused|ff_ln|conv_split|fp8|vae32|flash|flashlazy|flashpp|group|snsmall|insitu|lvl3|ffxt|halo|halo_l0|lanes|lanes2|lanes4 [repeats]"""
+only ever compared inside one process.  usage: ab_clip.py epipre|walk|rowmajor|ff_fused|ff_ln|conv_split|fp8|vae32|flash|flashlazy|flashpp|group|snsmall|insitu|lvl3|ffxt|halo|halo_l0|lanes|lanes2|lanes4 [repeats]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,10 +15,7 @@ eng = pipe.engine
 clip = synthetic_clip(T, H, W)
 nl, na = make_noise(T, H, W, 0)
 eng.set_inputs(DepthCrafter.prepare_input(None, clip), nl, na, np.stack(clip["intrinsics"], 0))
-if os.environ.get("UG_LN_FOLD"):
-    eng.set_ln_fold(int(os.environ["UG_LN_FOLD"]))
 setter = {"epipre": lambda on: eng.tune_force(-100 - (0 if on else 2097152), 0),     # round 5: epilogue operands prefetched during the K loop (192-row producer / consumer tiles)
-          "lnfold": lambda on: eng.set_ln_fold(1 if on else 0),                       # round 5: LayerNorms folded into their consumer GEMMs (levels 1 / 2)
           "walk": lambda on: eng.tune_force(-100 - (0 if on else 128), 0),           # round 5: XCD-owned tile runs (on) vs the round-strided walk
           "rowmajor": lambda on: eng.tune_force(-100 - (0 if on else 1048576), 0),  # round 5: row-major walk when a tile group fits the XCD's window anyway
           "conv_split": lambda on: eng.tune_force(-100 - (0 if on else 1024), 0), "group": lambda on: eng.tune_force(-100 - (0 if on else 32), 0),

@@ -33,7 +33,6 @@ d = lambda a, b: (np.abs(a - b).max(axis=(1, 2, 3, 4)) / scl)
 pipe = DepthCrafterPipelineHIP.from_state(su, sv, sc, cfgs=(u, v, c), workspace_bytes=3 << 30)
 eng = pipe.engine
 VARIANTS = [("default", lambda: None, lambda: None),
-            ("LayerNorm outputs not rounded (folded into the consumer GEMM, ln_fold 2)", lambda: eng.set_ln_fold(2), lambda: eng.set_ln_fold(0)),
             ("feed-forward as two GEMM launches (fp16 GEGLU intermediate through HBM)", lambda: eng.set_ff_fused(False), lambda: eng.set_ff_fused(True)),
             ("flash attention: reference maximum tracked per tile (variant 7: no lazy rescale / fp32 row sums)", lambda: eng.tune_flash(7), lambda: eng.tune_flash(-1)),
             ("VAE encoder in fp16 storage instead of float32-grade", lambda: eng.set_vae_encode_fp32(False), lambda: eng.set_vae_encode_fp32(True)),

@@ -19,8 +19,6 @@ if os.environ.get("UG_TUNE_KNOBS"):     # GEMM knob mask for this run (kernels/g
     eng.tune_force(-100 - int(os.environ["UG_TUNE_KNOBS"]), -1)
 if os.environ.get("UG_FP8"):
     eng.set_fp8_linears(True)           # BASELINE configs[4] option: MX-fp8 linear layers
-if os.environ.get("UG_LN_FOLD"):
-    eng.set_ln_fold(int(os.environ["UG_LN_FOLD"]))
 if os.environ.get("UG_NO_FF_FUSED"):
     eng.set_ff_fused(False)
 eng.run(1, 8)

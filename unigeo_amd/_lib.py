@@ -18,7 +18,7 @@ EXPORTS = [
     "ug_unet_config_default", "ug_vae_config_default", "ug_clip_config_default",
     "ug_create", "ug_destroy", "ug_last_error", "ug_workspace_peak",
     "ug_load_tensor", "ug_bind_unet", "ug_bind_vae", "ug_bind_clip",
-    "ug_dc_set_inputs", "ug_dc_run", "ug_dc_run_windows", "ug_dc_get_outputs", "ug_dc_device_ptrs", "ug_dc_set_trace", "ug_set_vae_encode_fp32", "ug_set_concurrency", "ug_set_coscheduled", "ug_set_fp8_linears", "ug_op_linear_mx8", "ug_set_ff_fused", "ug_set_ln_fold", "ug_op_proj_ln_linear", "ug_op_ff", "ug_op_ln_ff", "ug_bench_ff", "ug_bench_flash", "ug_tune_flash", "ug_tune_ff",
+    "ug_dc_set_inputs", "ug_dc_run", "ug_dc_run_windows", "ug_dc_get_outputs", "ug_dc_device_ptrs", "ug_dc_set_trace", "ug_set_vae_encode_fp32", "ug_set_concurrency", "ug_set_coscheduled", "ug_set_fp8_linears", "ug_op_linear_mx8", "ug_set_ff_fused", "ug_op_ff", "ug_op_ln_ff", "ug_bench_ff", "ug_bench_flash", "ug_tune_flash", "ug_tune_ff",
     "ug_eval_depth", "ug_eval_normal", "ug_clip_embed", "ug_vae_encode", "ug_vae_decode", "ug_unet_forward", "ug_normals_from_depth",
     "ug_op_linear", "ug_op_conv", "ug_op_conv_gn", "ug_op_groupnorm", "ug_op_layernorm", "ug_op_flash_attn",
     "ug_op_temporal_attn", "ug_op_attention_generic", "ug_op_flash_attn_dh", "ug_op_euler_step",
@@ -86,8 +86,6 @@ def load_library():
         lib.ug_set_concurrency.argtypes = [vp, ip]
         lib.ug_set_coscheduled.argtypes = [vp, ip]
         lib.ug_set_ff_fused.argtypes = [vp, ip]
-        lib.ug_set_ln_fold.argtypes = [vp, ip]
-        lib.ug_op_proj_ln_linear.argtypes = [vp, vp, ip, ip, vp, vp, ip, vp, vp, ip, vp, vp, C.c_float, vp, vp, ip, ip, ip, vp, vp, vp]
         lib.ug_bench_ff.argtypes = [vp, ip, ip, ip, ip, vp]
         lib.ug_bench_flash.argtypes = [vp, ip, ip, ip, ip, ip, vp]
         lib.ug_tune_flash.argtypes = [vp, ip]
@@ -301,23 +299,6 @@ class Engine:
         """This context shares the GPU with another clip in flight (a second context): drop the heuristics that fill the last round of one kernel at the
         price of extra launches / work (fused feed-forward tail split, last-round fill factor of the tile planner)."""
         self._ck(self.lib.ug_set_coscheduled(self.ctx, int(bool(on))))
-
-    def set_ln_fold(self, mode=0):
-        """LayerNorm folded into its consumer GEMM: 0 = LayerNorm launches (default), 1 = folded at M >= 4096, 2 = wherever the kernels can."""
-        self._ck(self.lib.ug_set_ln_fold(self.ctx, int(mode)))
-
-    def op_proj_ln_linear(self, A, Wp, bp, gamma, beta, W, bias, R=None, vec=None, rows_per_vec=1, eps=1e-5, geglu=False, mode=2):
-        """s = A Wp^T + bp (+ R) (+ vec[row // rows_per_vec]); y = (GEGLU of) LayerNorm(s) W^T + bias.  Returns (s, y, slots)."""
-        A = _f32(A); M, K0 = A.shape
-        Wp = _f32(Wp); Cc = Wp.shape[0]
-        W = _f32(W); N = W.shape[0]
-        s = np.empty((M, Cc), np.float32); y = np.empty((M, N // 2 if geglu else N), np.float32)
-        slots = C.c_int(0)
-        self._ck(self.lib.ug_op_proj_ln_linear(self.ctx, _ptr(A), M, K0, _ptr(Wp), _ptr(None if bp is None else _f32(bp)), Cc,
-                                                _ptr(None if R is None else _f32(R)), _ptr(None if vec is None else _f32(vec)), int(rows_per_vec),
-                                                _ptr(_f32(gamma)), _ptr(_f32(beta)), float(eps), _ptr(W), _ptr(None if bias is None else _f32(bias)), N,
-                                                int(bool(geglu)), int(mode), _ptr(s), _ptr(y), C.byref(slots)))
-        return s, y, slots.value
 
     def set_concurrency(self, lanes=2):
         """Independent chunks (VAE encode / decode chunks, CLIP tower) in flight on separate HIP streams; 1 = serial.  Bit-identical outputs."""

@@ -137,13 +137,6 @@ int ug_set_coscheduled(ug_ctx* x, int on) {
   x->c.lane_need.clear();
   return 0;
 }
-int ug_set_ln_fold(ug_ctx* x, int mode) {
-  UG_TRY(x, {
-    Ctx& c = x->c;
-    c.ln_fold = mode < 0 ? 0 : (mode > 2 ? 2 : mode); c.lane_need.clear();
-    if (c.ln_fold) fold_unet_layernorms(c);                        // the folded weight copies, once (needs ~15 % of the UNet's size in the persistent arena)
-  });
-}
 int ug_set_fp8_linears(ug_ctx* x, int on) {
   if (!x) return -1;
   x->c.fp8_linears = on ? 1 : 0; x->c.lane_need.clear();
@@ -812,90 +805,6 @@ int ug_op_layernorm(ug_ctx* x, const float* xin, int M, int C, float eps, const 
   });
 }
 
-// Projection -> LayerNorm -> linear, the round-5 folded forms against the three-pass form (tests/test_ops_gpu.py::test_layernorm_folded_into_consumer_gemm):
-//   s = A Wp^T + bp (+ R) (+ vec[row / rows_per_vec]),  y = (GEGLU of) LayerNorm(s) W^T + bias
-// mode 0: projection, LayerNorm launch (adds vec, writes s), GEMM - rounds 1 - 4;  mode 1: projection, statistics-only LayerNorm launch (adds vec, writes s),
-// GEMM on the raw s with the normalisation in its epilogue;  mode 2: the projection adds vec itself (per-row-block bias2) and leaves row partial sums,
-// k_rowstat_finalize, folded GEMM.  slots_out = row-partial slots the projection wrote (mode 2; 0 = it declined and the statistics launch ran instead).
-int ug_op_proj_ln_linear(ug_ctx* x, const float* A, int M, int K0, const float* Wp, const float* bp, int C, const float* R, const float* vec, int rows_per_vec,
-                         const float* gamma, const float* beta, float eps, const float* W, const float* bias, int N, int geglu, int mode,
-                         float* s_out, float* y_out, int* slots_out) {
-  UG_TRY(x, {
-    Ctx& c = x->c; Scope sc(c);
-    std::vector<float> Wq, bq;
-    const float* Wu = W; const float* bu = bias;
-    if (geglu) {   // same row interleave as bind_geglu
-      const int inner = N / 2;
-      Wq.resize((size_t)N * C); if (bias) bq.resize(N);
-      for (int v = 0; v < N; ++v) {
-        const int blk = v / 16, wv = v % 16;
-        const int src = wv < 8 ? blk * 8 + wv : inner + blk * 8 + (wv - 8);
-        memcpy(&Wq[(size_t)v * C], &W[(size_t)src * C], (size_t)C * 4);
-        if (bias) bq[v] = bias[src];
-      }
-      Wu = Wq.data(); if (bias) bu = bq.data();
-    }
-    const int Nout = geglu ? N / 2 : N;
-    f16* dA = up16(c, A, (long)M * K0); f16* dWp = up16(c, Wp, (long)C * K0); f16* dbp = up16_opt(c, bp, C);
-    f16* dR = up16_opt(c, R, (long)M * C);
-    const int nv = vec ? (M + rows_per_vec - 1) / rows_per_vec : 0;
-    f16* dvec = up16_opt(c, vec, (long)nv * C);
-    f16* dg = up16(c, gamma, C); f16* dbeta = up16(c, beta, C);
-    f16* dW = up16(c, Wu, (long)N * C); f16* db = up16_opt(c, bu, N);
-    f16* s0 = c.ws.get<f16>((long)M * C); f16* s1 = c.ws.get<f16>((long)M * C); f16* t1 = c.ws.get<f16>((long)M * C);
-    f16* dY = c.ws.get<f16>((long)M * Nout);
-    float2* stat = (float2*)c.ws.get<float>((long)M * 2);
-    const int cap = 40;
-    float2* part = (float2*)c.ws.get<float>((long)M * cap * 2);
-    f16* wf = c.ws.get<f16>((long)N * C); float* fs = c.ws.get<float>(N); float* fb = c.ws.get<float>(N);
-    auto plan = [&](GemmP& p) { gemm_apply_tune(p, c.tune); int cf, sp; gemm_plan(p, 1, &cf, &sp); p.cfg_p1 = cf + 1; p.splitk = sp; if (sp > 1) p.partial = c.ws.get<float>((long)sp * p.M * p.N); };
-    GemmP pp; memset(&pp, 0, sizeof(pp));
-    pp.A0 = dA; pp.C0 = K0; pp.M = M; pp.N = C; pp.K = K0; pp.W = dWp; pp.ldw = K0; pp.bias = dbp; pp.R1 = dR; pp.ldr1 = C; pp.c0 = 1.f; pp.c1 = 1.f;
-    pp.ldo = C; pp.zero = c.zero; pp.nb_inner = 1;
-    GemmP pc; memset(&pc, 0, sizeof(pc));
-    pc.C0 = C; pc.M = M; pc.N = N; pc.K = C; pc.ldw = C; pc.c0 = 1.f; pc.flags = geglu ? UG_F_GEGLU : 0; pc.Out = dY; pc.ldo = Nout; pc.zero = c.zero; pc.nb_inner = 1;
-    int slots = 0;
-    const f16* s_final = s0;
-    if (mode == 0) {
-      pp.Out = s0; plan(pp); launch_gemm(pp, 1, c.stream);
-      LayerNormP l; memset(&l, 0, sizeof(l));
-      l.X = s0; l.Y = t1; l.M = M; l.C = C; l.eps = eps; l.gamma = dg; l.beta = dbeta;
-      if (dvec) { l.addvec = dvec; l.rows_per_vec = rows_per_vec; l.Xout = s1; s_final = s1; }
-      launch_layernorm(l, c.stream);
-      pc.A0 = t1; pc.W = dW; pc.bias = db; plan(pc); launch_gemm(pc, 1, c.stream);
-    } else {
-      launch_fold_ln_weights(dW, db, dg, dbeta, wf, fs, fb, N, C, c.stream);
-      bool have = false;
-      if (mode == 2) {
-        GemmP q = pp; q.Out = s1; q.want_ext = 1; plan(q);
-        int want = 0;
-        if (gemm_epilogue_ext_ok(q, 1, &want) && want <= cap) {
-          q.row_part = part;
-          UG_CHECK(hipMemsetAsync(part, 0x7f, (size_t)M * cap * sizeof(float2), c.stream));   // poison (3.4e38): a slot the epilogue is counted for but never writes shows in y
-          if (dvec) { q.bias2 = dvec; q.bias2_rows = rows_per_vec >= M ? 0 : rows_per_vec; }
-          launch_gemm(q, 1, c.stream, nullptr, &slots);
-          s_final = s1; have = true;
-          if (slots > 0) launch_rowstat_finalize(part, slots, M, C, eps, stat, c.stream);
-          else { LayerNormP l; memset(&l, 0, sizeof(l)); l.X = s1; l.M = M; l.C = C; l.eps = eps; l.gamma = dg; l.beta = dbeta; l.stat_out = stat; launch_layernorm(l, c.stream); }
-        }
-      }
-      if (!have) {
-        pp.Out = s0; plan(pp); launch_gemm(pp, 1, c.stream);
-        LayerNormP l; memset(&l, 0, sizeof(l));
-        l.X = s0; l.M = M; l.C = C; l.eps = eps; l.gamma = dg; l.beta = dbeta; l.stat_out = stat;
-        if (dvec) { l.addvec = dvec; l.rows_per_vec = rows_per_vec; l.Xout = s1; s_final = s1; }
-        launch_layernorm(l, c.stream);
-      }
-      pc.A0 = s_final; pc.W = wf; pc.ln_stat = stat; pc.ln_s = fs; pc.ln_bias = fb; pc.want_ext = 2; plan(pc);
-      UG_REQUIRE(gemm_epilogue_ext_ok(pc, 1), "ug_op_proj_ln_linear: the consumer's tile cannot take the LayerNorm fold");
-      launch_gemm(pc, 1, c.stream);
-    }
-    if (slots_out) *slots_out = slots;
-    if (s_out) down16(c, s_final, s_out, (long)M * C);
-    down16(c, dY, y_out, (long)M * Nout);
-  });
-}
-
 int ug_op_flash_attn(ug_ctx* x, const float* qkv, int B, int H, int S, float* out) {
   UG_TRY(x, {
     Ctx& c = x->c; Scope sc(c);
@@ -995,14 +904,6 @@ int ug_bench_gemm(ug_ctx* x, int M, int N, int K, int conv, int T, int Hi, int W
     if (getenv("UG_BENCH_GEGLU") && !conv && N % 128 == 0) { p.flags |= UG_F_GEGLU; p.ldo = N / 2; }   // A/B aid: GEGLU epilogue
     if (getenv("UG_BENCH_R1")) { p.R1 = Os[nbuf - 1]; p.ldr1 = N; p.c1 = 1.f; }                          // A/B aid: a residual operand in the epilogue
     if (getenv("UG_BENCH_NOBIAS")) p.bias = nullptr;
-    if (getenv("UG_BENCH_LNF") && !conv) {   // A/B aid: the LayerNorm-fold epilogue (GemmP::ln_stat) on dummy statistics - timing only
-      float2* st = (float2*)c.ws.get<float>((long)M * 2); float* ls = c.ws.get<float>(N); float* lb = c.ws.get<float>(N);
-      UG_CHECK(hipMemsetAsync(st, 0, (size_t)M * 8, c.stream)); UG_CHECK(hipMemsetAsync(ls, 0, (size_t)N * 4, c.stream)); UG_CHECK(hipMemsetAsync(lb, 0, (size_t)N * 4, c.stream));
-      p.bias = nullptr; p.ln_stat = st; p.ln_s = ls; p.ln_bias = lb; p.want_ext = 2;
-    }
-    float2* rpart = nullptr;
-    if (getenv("UG_BENCH_ROWPART") && !conv) { rpart = (float2*)c.ws.get<float>((long)M * 40 * 2); p.row_part = rpart; p.want_ext = 1; }   // ... the row partial sums (GemmP::row_part)
-    if (getenv("UG_BENCH_WANTEXT")) p.want_ext = 1;                                                       // ... only the planner's hint (tile choice without the extension)
     gemm_apply_tune(p, c.tune);
     int cf = cfg, sp = split;
     if (cf < 0 || sp < 1) { int c2, s2; gemm_plan(p, 1, &c2, &s2); if (cf < 0) cf = c2; if (sp < 1) sp = s2; }
@@ -1010,11 +911,10 @@ int ug_bench_gemm(ug_ctx* x, int M, int N, int K, int conv, int T, int Hi, int W
     if (sp > 1) p.partial = c.ws.get<float>((long)sp * M * N);
     unsigned* trace = nullptr;
     if (getenv("UG_GEMM_TRACE")) { trace = c.ws.get<unsigned>(3 * 24 * 5); UG_CHECK(hipMemsetAsync(trace, 0, 3 * 24 * 5 * 4, c.stream)); p.trace = trace; }
-    int rslots = 0;
-    for (int i = 0; i < 2; ++i) launch_gemm(p, 1, c.stream, nullptr, rpart ? &rslots : nullptr);
+    for (int i = 0; i < 2; ++i) launch_gemm(p, 1, c.stream);
     hipEvent_t e0, e1; UG_CHECK(hipEventCreate(&e0)); UG_CHECK(hipEventCreate(&e1));
     UG_CHECK(hipEventRecord(e0, c.stream));
-    for (int i = 0; i < iters; ++i) { p.A0 = As[i % nbuf]; p.A1 = A1s[i % nbuf]; p.Out = Os[i % nbuf]; launch_gemm(p, 1, c.stream, nullptr, rpart ? &rslots : nullptr); }
+    for (int i = 0; i < iters; ++i) { p.A0 = As[i % nbuf]; p.A1 = A1s[i % nbuf]; p.Out = Os[i % nbuf]; launch_gemm(p, 1, c.stream); }
     UG_CHECK(hipEventRecord(e1, c.stream)); UG_CHECK(hipEventSynchronize(e1));
     float ms; UG_CHECK(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

@@ -87,17 +87,6 @@ struct GemmP {
   // launch_gemm) and per column the sum / sum of squares of the fp16 values stored, stat_part[blk * N + n]; stat_hw = output rows per frame (blocks
   // must not straddle frames).  launch_gemm declines (reports rb = 0, writes nothing) when the chosen kernel cannot: split-K, ragged tiles, ...
   float2* stat_part; int stat_hw;
-  // LayerNorm folded into its consumer GEMM (round 5; dense launches through tile_epilogue only - launch_gemm checks): A is the RAW activation x, W holds the
-  // centred folded weights Wf = fp16(gamma o W0 - rowmean(gamma o W0)) (k_fold_ln_weights: x Wf^T = (x - mean) (gamma o W0)^T), and the epilogue scales row m by
-  // rstd[m] = ln_stat[m].y and adds ln_bias[n] = bias[n] + sum_k beta[k] W0[n][k] (fp32; `bias` must be null) before GEGLU / c0 / residuals.  ln_s is not read
-  // by the kernels (the row sums the fp16 rounding leaves of Wf, ~1e-3: kept for the tests).
-  const float2* ln_stat; const float* ln_s; const float* ln_bias;
-  // Row statistics of the OUTPUT for the LayerNorm that follows (round 5): per row m and per slot = (column tile, wave column) the sum / sum of squares of
-  // the fp16 values stored, row_part[slot * M + m]; launch_gemm reports the slot count (0 = the chosen kernel cannot: split-K, GEGLU, streaming / halo kernels).
-  float2* row_part;
-  int want_ext;          // gemm_plan: pick a tile whose kernel is instantiated with these extensions (set by the caller that will set ln_stat / row_part / bias2_rows):
-                         // 1 = any of them, 2 = the LayerNorm fold alone (the 256 x 256 loader tile can then stay)
-  int bias2_rows;        // 0: bias2 is one [N] vector; r > 0: output row m adds bias2[(m / r) * N + n] - the per-frame cross-attention row added to the residual stream
 };
 // tuning overrides (A/B tools and the tile-config tests; ug_tune_force sets them on ONE context, the engine copies them into every GemmP):
 // cfg / split -1 = planner's choice; knobs = bit mask documented in kernels/gemm.hip
@@ -106,7 +95,7 @@ static inline void gemm_apply_tune(GemmP& p, const GemmTune& t) { p.tune_cfg_p1 
 void launch_gemm_mx8(const GemmP& p, hipStream_t s);   // dense only; C0 = lda and ldw in BYTES (= elements)
 // fp16 [M, K] (row stride ldx) -> e4m3 bytes [M, K] + e8m0 scales (layout above, ld_s >= round_up(M, 256)); K % 128 == 0
 void launch_quant_mx8(const f16* x, long ldx, long M, int K, unsigned char* q, unsigned* scales, long ld_s, hipStream_t s);
-void launch_gemm(const GemmP& p, int batch, hipStream_t s, int* stat_rb = nullptr, int* row_slots = nullptr);   // stat_rb: rows per statistics block written (0 = none), see GemmP::stat_part; row_slots: GemmP::row_part slots written (0 = none)
+void launch_gemm(const GemmP& p, int batch, hipStream_t s, int* stat_rb = nullptr);   // stat_rb: rows per statistics block written (0 = none), see GemmP::stat_part
 // weight-stationary streaming GEMM for K = 320, N in {320, 640, 960} (kernels/gemm_stream.hip; tile config 80): dense, fp16 out, bias + one residual
 bool gemm_stream_supported(const GemmP& p, int batch);
 void launch_gemm_stream(const GemmP& p, hipStream_t s);
@@ -114,7 +103,6 @@ void launch_gemm_stream(const GemmP& p, hipStream_t s);
 bool conv_halo_supported(const GemmP& p, int batch, int bm, int bn);
 void launch_conv_halo(const GemmP& p, int bm, int bn, hipStream_t s);
 void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out);   // heuristic used when cfg/splitk are 0
-bool gemm_epilogue_ext_ok(const GemmP& p, int batch, int* slots = nullptr);   // would this launch accept GemmP::ln_stat / row_part / bias2_rows? (+ row_part slot count)
 
 // Fused GEGLU feed-forward (kernels/ff_fused.hip): Out = c0 * (GEGLU(X W1^T + b1) W2^T + b2) + c1 R1 + c2 R2, all [M, C] row-major (ld = C);
 // W1 [8C][C] / b1 [8C] in the bound GEGLU row order (blocks of 16 rows = [8 value | 8 gate]), W2 [C][4C], C in {64,...,320}
@@ -160,15 +148,8 @@ struct LayerNormP {
   long row0;                                        // index of row 0 in the addvec numbering (a row sub-range of a larger tensor)
   // optional MX-fp8 output INSTEAD of Y (fp8 linear path): e4m3 bytes [M][C] + e8m0 block scales, layout of launch_quant_mx8 (C % 128 == 0)
   unsigned char* Y8; unsigned* S8; long ld_s8;
-  // statistics-only form (round 5, LayerNorm folded into the consumer GEMM): stat_out[m] = (mean, rstd) of x' = X (+ addvec), nothing normalised, Y unused;
-  // Xout still receives x' when given
-  float2* stat_out;
 };
 void launch_layernorm(const LayerNormP& p, hipStream_t s);
-// (mean, rstd)[m] from the row partial sums a GEMM epilogue wrote (GemmP::row_part, [slots][M]); C = row length
-void launch_rowstat_finalize(const float2* part, int slots, long M, int C, float eps, float2* stat, hipStream_t s);
-// LayerNorm folded into a linear layer, at bind time: Wf[n][k] = fp16(W[n][k] * gamma[k] - rowmean_n); s[n] = sum_k float(Wf[n][k]) (~0); bf[n] = bias[n] + sum_k beta[k] * W[n][k]
-void launch_fold_ln_weights(const f16* W, const f16* bias, const f16* gamma, const f16* beta, f16* Wf, float* s_out, float* b_out, int N, int K, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // Attention (kernels/attn.hip)

@@ -35,8 +35,6 @@ class Arena {
 };
 
 struct Lin { const f16* w = nullptr; const f16* b = nullptr; int in = 0, out = 0;
-             // LayerNorm folded in (round 5, fold_ln at bind time): CENTRED folded weights wf = fp16(gamma o w - rowmean(gamma o w)) so that x wf^T = (x - mean)(gamma o w)^T, fb[n] = b[n] + sum_k beta[k] w[n][k]; the epilogue computes rstd[m] acc + fb[n] - no mean term (fs is kept for the kernels' argument checks, never read) (GemmP::ln_stat)
-             const f16* wf = nullptr; const float* fs = nullptr; const float* fb = nullptr;
              // optional MX-fp8 copy of the weight (kernels/mx8.hip): e4m3 bytes [out][in] + e8m0 block scales [in/128][ld_sw8] dwords
              const unsigned char* w8 = nullptr; const unsigned* sw8 = nullptr; long ld_sw8 = 0; };
 struct Conv { const f16* w = nullptr; const f16* b = nullptr; int cin = 0, cinp = 0, cout = 0, kt = 1, ky = 1, kx = 1;
@@ -172,7 +170,6 @@ struct Ctx {
   int cur_lane = 0;          // 0 = main stream, l + 1 = lane l (run_lanes)
   int cosched = 0;           // this context shares the GPU with another clip in flight (ug_set_coscheduled): heuristics that trade extra launches / work for a fuller
                              // last round of ONE kernel are off - the fused feed-forward takes all rows (no two-GEMM tail), the tile planner ignores the last-round fill
-  int ln_fold = 0;           // LayerNorm folded into its consumer GEMM (engine.hip: transformer_forward): 0 off (default: measured +14 ms per clip), 1 at M >= 4096, 2 wherever the kernels can (tests)
   int ff_variant = 0, flash_variant = -1;   // ug_tune_ff / ug_tune_flash: per-context A/B overrides copied into FFusedP / FlashP (0 / -1 = the defaults)
   GemmTune tune;             // ug_tune_force: tile-config / split-K / knob overrides for THIS context's GEMM launches (tests, A/B tools)
 };
@@ -182,7 +179,6 @@ void* pinned(Ctx& c, int slot, size_t bytes);   // page-locked staging buffer of
 // ---- binding ----
 void upload_raw(Ctx& c, const std::string& name, int dtype, const std::vector<long>& shape, const void* host);
 void bind_unet(Ctx& c, const UNetCfg& cfg, const std::string& prefix);
-void fold_unet_layernorms(Ctx& c);   // LayerNorm-folded weight copies for Ctx::ln_fold > 0 (made on demand)
 void bind_vae(Ctx& c, const VAECfg& cfg, const std::string& prefix);
 void bind_clip(Ctx& c, const CLIPCfg& cfg, const std::string& prefix);
 void finish_binding(Ctx& c, const std::string& prefix);   // fail on unused tensors, free raw

@@ -200,19 +200,7 @@ struct Epi {
   const unsigned char* a8 = nullptr; const unsigned* sa8 = nullptr; long ld_sa8 = 0;   // A already in MX-fp8 (written by the producing LayerNorm)
   float alg = 1.f;   // algorithmic / executed FLOPs of this launch (0.5 for the K-doubled hi/lo-pair GEMMs of the float32-grade encoder)
   struct StatPart* so = nullptr; int stat_hw = 0;   // GroupNorm statistics of the output from the epilogue (stat_hw: rows per frame of a dense output)
-  // round 5, LayerNorm folded into its consumer: ln_stat = (mean, rstd) per row of the RAW input (the layer's folded weights Lin::wf / fs / fb are used);
-  // rs = row partial sums of THIS output for the LayerNorm that follows; bias2_rows > 0: bias2 is [M / bias2_rows][N], one row per block of output rows
-  const float2* ln_stat = nullptr; struct RowStat* rs = nullptr; int bias2_rows = 0;
 };
-// Row statistics handed from a producing GEMM's epilogue (GemmP::row_part) to the LayerNorm-folded GEMM that consumes the tensor: part = [cap][M] slots,
-// slots = written by the producer (0: it could not - the caller then runs the statistics-only LayerNorm launch), stat = (mean, rstd)[M]
-struct RowStat { float2* part = nullptr; int cap = 0, slots = 0; float2* stat = nullptr; long M = 0; };
-static RowStat rowstat_alloc(Ctx& c, long M) {
-  RowStat r; r.cap = 40; r.M = M;                    // 1280 columns on 64-column tiles x 2 wave columns / 128-column tiles x 4
-  r.part = (float2*)c.ws.get<float>(M * r.cap * 2);
-  r.stat = (float2*)c.ws.get<float>(M * 2);
-  return r;
-}
 // GroupNorm statistics handed from the producing GEMM's epilogue to the GroupNorm that follows (GemmP::stat_part): allocated by the caller next to the
 // tensor, filled by conv() / linear() when the chosen kernel can (rb = rows per block, 0 = not written: groupnorm() then runs its statistics pass)
 struct StatPart { float2* part = nullptr; int rb = 0; };
@@ -227,7 +215,7 @@ static StatPart stat_alloc(Ctx& c, long M, int N, int T, int hw, int G, int temp
   return s;
 }
 
-static void run_gemm(Ctx& c, GemmP p, int batch, const char* tag, float alg = 1.f, StatPart* so = nullptr, int stat_hw = 0, RowStat* rs = nullptr) {
+static void run_gemm(Ctx& c, GemmP p, int batch, const char* tag, float alg = 1.f, StatPart* so = nullptr, int stat_hw = 0) {
   p.zero = c.zero;
   gemm_apply_tune(p, c.tune);
   if (p.nb_inner < 1) p.nb_inner = 1;
@@ -248,13 +236,7 @@ static void run_gemm(Ctx& c, GemmP p, int batch, const char* tag, float alg = 1.
                                         (p.R1 ? (double)p.M * nout : 0.0) + (p.R2 ? (double)p.M * nout : 0.0));
     ProfScope ps(c, nm, 2.0 * p.M * p.N * (double)p.K * batch * (p.up_phase ? 2.25 : 1.0) * alg, bytes);
     if (so && so->part) { p.stat_part = so->part; p.stat_hw = p.conv ? p.Ho * p.Wo : stat_hw; }
-    int slots = 0;
-    if (rs && rs->part) {
-      int want = 0;
-      if (gemm_epilogue_ext_ok(p, batch, &want) && want <= rs->cap && !(p.flags & UG_F_GEGLU)) p.row_part = rs->part;
-    }
-    launch_gemm(p, batch, c.stream, so && so->part ? &so->rb : nullptr, p.row_part ? &slots : nullptr);
-    if (rs) rs->slots = slots;
+    launch_gemm(p, batch, c.stream, so && so->part ? &so->rb : nullptr);
   }
   c.ws.release(mk);
 }
@@ -311,28 +293,14 @@ static void linear(Ctx& c, const f16* A, long M, const Lin& l, f16* out, const E
     return;
   }
   p.A0 = A; p.C0 = (int)(lda ? lda : l.in); p.M = (int)M; p.N = l.out; p.K = l.in;
-  p.W = l.w; p.ldw = l.in; p.bias = l.b; p.bias2 = e.bias2; p.bias2_rows = e.bias2_rows;
-  if (e.ln_stat) {   // A is the raw stream: LayerNorm(A) W^T + b = rstd (A Wf^T) + fb in the epilogue, Wf = the centred folded weights (engine.h: Lin::wf)
-    UG_REQUIRE(l.wf && l.fs && l.fb, "linear: LayerNorm fold requested for a layer that was not folded at bind time");
-    p.W = l.wf; p.bias = nullptr; p.ln_stat = e.ln_stat; p.ln_s = l.fs; p.ln_bias = l.fb;
-  }
+  p.W = l.w; p.ldw = l.in; p.bias = l.b; p.bias2 = e.bias2;
   p.R1 = e.R1; p.ldr1 = e.ldr1; p.c1 = e.c1; p.R2 = e.R2; p.ldr2 = e.ldr2; p.c2 = e.c2; p.c0 = e.c0;
   p.act = e.act; p.flags = e.flags;
   const int nout = (e.flags & UG_F_GEGLU) ? l.out / 2 : l.out;
   p.Out = out; p.ldo = ldo ? ldo : nout;
   if (p.R1 && !p.ldr1) p.ldr1 = nout;
   if (p.R2 && !p.ldr2) p.ldr2 = nout;
-  p.want_ext = (e.rs || e.bias2_rows > 0) ? 1 : (e.ln_stat ? 2 : 0);
-  run_gemm(c, p, 1, e.ln_stat ? "gemm_linear_lnf" : "gemm_linear", e.alg, e.so, e.stat_hw, e.rs);
-}
-// would linear(A[M, l.in], l, flags) take the round-5 epilogue extensions (LayerNorm fold, row partial sums, per-row bias2) on the tile the planner picks?
-static bool lin_ext_ok(Ctx& c, long M, const Lin& l, int flags, int want = 1) {
-  GemmP p; memset(&p, 0, sizeof(p));
-  p.C0 = l.in; p.M = (int)M; p.N = l.out; p.K = l.in; p.ldw = l.in; p.flags = flags; p.nb_inner = 1;
-  const int nout = (flags & UG_F_GEGLU) ? l.out / 2 : l.out;
-  p.ldo = nout; p.ldr1 = nout; p.ldr2 = nout; p.c0 = 1.f; p.want_ext = want;
-  gemm_apply_tune(p, c.tune);
-  return gemm_epilogue_ext_ok(p, 1);
+  run_gemm(c, p, 1, "gemm_linear", e.alg, e.so, e.stat_hw);
 }
 
 // implicit-GEMM convolution over channels-last sources
@@ -403,25 +371,6 @@ static void layernorm(Ctx& c, const f16* x, long M, const Norm& n, f16* y, const
   launch_layernorm(p, c.stream);
 }
 
-// statistics-only LayerNorm launch: stat[m] = (mean, rstd) of x' = x (+ addvec row), x' written to xout when given (the fall-back / add-vector form of the
-// LayerNorm fold: one read of x instead of LayerNorm's read + write)
-static void layernorm_stats(Ctx& c, const f16* x, long M, const Norm& n, float2* stat, const f16* addvec = nullptr, long rows_per_vec = 1, f16* xout = nullptr) {
-  LayerNormP p; memset(&p, 0, sizeof(p));
-  p.X = x; p.M = (int)M; p.C = n.c; p.eps = n.eps; p.gamma = n.g; p.beta = n.b;
-  p.addvec = addvec; p.rows_per_vec = (int)rows_per_vec; p.Xout = xout; p.stat_out = stat;
-  ProfScope ps(c, "layernorm_stats", 0, (double)M * n.c * 2.0 * (addvec ? 2.0 : 1.0));
-  launch_layernorm(p, c.stream);
-}
-// (mean, rstd) of the rows of the tensor a GEMM just wrote: from its epilogue's partial sums when it left them (rs.slots > 0), else by the statistics-only launch
-static const float2* rowstat_get(Ctx& c, RowStat& rs, const f16* x, long M, const Norm& n) {
-  if (rs.slots > 0) {
-    ProfScope ps(c, "layernorm_stats", 0, (double)M * rs.slots * 8.0);
-    launch_rowstat_finalize(rs.part, rs.slots, M, n.c, n.eps, rs.stat, c.stream);
-  } else {
-    layernorm_stats(c, x, M, n, rs.stat);
-  }
-  return rs.stat;
-}
 
 // ------------------------------------------------------------------ raw tensor registry
 void upload_raw(Ctx& c, const std::string& name, int dtype, const std::vector<long>& shape, const void* host) {
@@ -531,28 +480,6 @@ static Lin bind_geglu(Ctx& c, const std::string& p, int in, int inner) {
   c.persist.release(mk);
   l.w = w; l.b = b;
   return l;
-}
-// LayerNorm `n` folded into the linear layer `l` that consumes its output (Lin::wf / fs / fb; kernels/misc.hip: k_fold_ln_weights).  The rows of l.w may be
-// fused (q|k|v) or re-ordered (GEGLU): the fold is per row.
-static void fold_ln(Ctx& c, Lin& l, const Norm& n) {
-  if (n.c != l.in || l.in % 64 != 0 || l.out % 64 != 0) return;
-  f16* wf = c.persist.get<f16>((long)l.out * l.in);
-  float* fs = c.persist.get<float>(l.out); float* fb = c.persist.get<float>(l.out);
-  launch_fold_ln_weights(l.w, l.b, n.g, n.b, wf, fs, fb, l.out, l.in, c.stream);
-  l.wf = wf; l.fs = fs; l.fb = fb;
-}
-// The five LayerNorms of every transformer block pair folded into the projections that consume them (transformer_forward, Ctx::ln_fold): 27 C^2 fp16 weights per
-// pair, 0.67 GB for the full UNet - made when the folded path is first switched on, not at bind time (the default path never reads them).
-void fold_unet_layernorms(Ctx& c) {
-  if (!c.unet.bound) return;
-  auto fold = [&](Transformer& t) {
-    if (t.qkv1.wf || !t.qkv1.w) return;
-    fold_ln(c, t.qkv1, t.ln1); fold_ln(c, t.ff1, t.ln3); fold_ln(c, t.ffin1, t.ln_in); fold_ln(c, t.tqkv, t.tln1); fold_ln(c, t.tff1, t.tln3);
-  };
-  for (auto& d : c.unet.down) for (auto& t : d.attn) fold(t);
-  for (auto& u : c.unet.up) for (auto& t : u.attn) fold(t);
-  fold(c.unet.mid_attn);
-  UG_CHECK(hipStreamSynchronize(c.stream));
 }
 static inline int pad8(int x) { return (x + 7) & ~7; }
 // MX-fp8 copy of a bound linear layer's weight (rows are quantised independently along K, so fused / re-ordered rows stay valid)
@@ -704,7 +631,6 @@ static Transformer bind_transformer(Ctx& c, const std::string& p, int C, int hea
   const float mix = raw_scalar(c, p + ".time_mixer.mix_factor");
   t.alpha = 1.f / (1.f + expf(-mix));
   for (Lin* l : {&t.proj_in, &t.proj_out, &t.qkv1, &t.o1, &t.ff1, &t.ff2, &t.ffin1, &t.ffin2, &t.tqkv, &t.to1, &t.tff1, &t.tff2}) quant_lin(c, *l);
-  // (the LayerNorm-folded copies of qkv1 / ff1 / ffin1 / tqkv / tff1 are made on demand: fold_unet_layernorms, called by ug_set_ln_fold)
   return t;
 }
 
@@ -1097,27 +1023,16 @@ static f16* transformer_forward(Ctx& c, const Transformer& tr, const f16* x, int
   const size_t mk = c.ws.mark();
   f16* t1 = c.ws.get<f16>(M * C);
   groupnorm(c, x, C, nullptr, 0, T, HW, G, tr.gn, 0, 0, t1, in_stats);
-  f16* h0 = c.ws.get<f16>(M * C);     // proj_in is launched below, once the fold decision of its consumer is known
+  f16* h0 = c.ws.get<f16>(M * C);
   // fp8 linear path: the LayerNorms feeding a linear layer write MX-fp8 directly (no fp16 copy, no separate quantiser pass)
   const bool q8 = c.fp8_linears && !getenv("UG_NO_LNQ") && C % 128 == 0 && M >= 256 && tr.qkv1.w8 && tr.ff1.w8 && tr.ffin1.w8 && tr.tqkv.w8 && tr.tff1.w8;
   QAct qa; if (q8) qa = qact_alloc(c, M, C);
   const QAct* qp = q8 ? &qa : nullptr;
   auto qepi = [&](Epi e) { if (q8) { e.a8 = qa.a8; e.sa8 = qa.sa; e.ld_sa8 = qa.ld; } return e; };
-  // Round 5: a LayerNorm whose consumer is a tiled GEMM runs FOLDED into that GEMM (GemmP::ln_stat: the GEMM reads the raw stream, its epilogue applies
-  // rstd (acc - mean s) + b'); the row statistics come from the partial sums the PRODUCING GEMM's epilogue leaves (GemmP::row_part + k_rowstat_finalize) or, where
-  // the producer cannot (fused / streaming kernels, split-K) or the stream first takes a broadcast row that an earlier tensor must not see, from the
-  // statistics-only LayerNorm launch.  The cross-attention row is added by the producing projection (GemmP::bias2_rows) instead of by the LayerNorm pass.
-  // Ctx::ln_fold: 0 off, 1 where it pays (M >= 4096), 2 wherever the kernels can (tests).  Narrow level: the fused feed-forward / streaming forms keep their own.
-  auto fold_site = [&](const Lin& l, int flags) {
-    return c.ln_fold && !q8 && l.wf && (c.ln_fold >= 2 || M >= 4096) && lin_ext_ok(c, M, l, flags, 2);
-  };
   // ---- spatial block
   f16* qkv = c.ws.get<f16>(M * 3 * C);
-  const bool f1 = fold_site(tr.qkv1, 0);
-  RowStat rs1; if (f1) rs1 = rowstat_alloc(c, M);
-  { Epi e; if (f1) e.rs = &rs1; linear(c, t1, M, tr.proj_in, h0, e); }
-  if (f1) { Epi e; e.ln_stat = rowstat_get(c, rs1, h0, M, tr.ln1); linear(c, h0, M, tr.qkv1, qkv, e); }
-  else ln_linear(c, h0, M, tr.ln1, t1, tr.qkv1, qkv, qp);
+  linear(c, t1, M, tr.proj_in, h0);
+  ln_linear(c, h0, M, tr.ln1, t1, tr.qkv1, qkv, qp);
   f16* ao = c.ws.get<f16>(M * C);
   {
     FlashP p; p.Q = qkv; p.K = qkv + C; p.V = qkv + 2 * C; p.ldq = p.ldk = p.ldv = 3 * C; p.O = ao; p.ldo = C;
@@ -1132,48 +1047,13 @@ static f16* transformer_forward(Ctx& c, const Transformer& tr, const f16* x, int
   f16* h2 = c.ws.get<f16>(M * C);
   f16* ffm = c.ws.get<f16>(M * 4 * C);
   f16* hs = c.ws.get<f16>(M * C);
-  // y = FF(LayerNorm(s)) + residuals with s = attn_out(ao) + res + vec:  folded form of "projection, LayerNorm (+ broadcast row), GEGLU pair"
-  auto attn_out_ff = [&](const Lin& o, const f16* res, const f16* vec, long rows_per_vec, f16* tmp, f16* s_out, const Norm& ln, const Lin& fa, const Lin& fb,
-                         f16* y, const Epi& e2) {
-    RowStat rs = rowstat_alloc(c, M);
-    const float2* st;
-    if (lin_ext_ok(c, M, o, 0)) {     // the projection adds the broadcast row itself and leaves the row sums of what it stores
-      Epi e; e.R1 = res; e.bias2 = vec; e.bias2_rows = rows_per_vec >= M ? 0 : (int)rows_per_vec; e.rs = &rs;
-      linear(c, ao, M, o, s_out, e);
-      st = rowstat_get(c, rs, s_out, M, ln);
-    } else {
-      { Epi e; e.R1 = res; linear(c, ao, M, o, tmp, e); }
-      layernorm_stats(c, tmp, M, ln, rs.stat, vec, rows_per_vec, s_out);
-      st = rs.stat;
-    }
-    { Epi e; e.flags = UG_F_GEGLU; e.ln_stat = st; linear(c, s_out, M, fa, ffm, e); }
-    linear(c, ffm, M, fb, y, e2);
-  };
-  const bool ffu_sp = ff_pair_fusable(c, M, tr.ff1, tr.ff2, Epi());     // the narrow level's fused feed-forward (with or without its in-kernel LayerNorm) keeps the site
-  if (!ffu_sp && fold_site(tr.ff1, UG_F_GEGLU)) {
-    Epi e; e.R1 = h2;
-    attn_out_ff(tr.o1, h0, tr.cross_sp, HW, h1, h2, tr.ln3, tr.ff1, tr.ff2, hs, e);
-  } else {
-    { Epi e; e.R1 = h0; linear(c, ao, M, tr.o1, h1, e); }
-    { Epi e; e.R1 = h2; ln_ff(c, h1, M, tr.ln3, tr.cross_sp, HW, h2, t1, tr.ff1, tr.ff2, ffm, hs, e, qp); }
-  }
+  { Epi e; e.R1 = h0; linear(c, ao, M, tr.o1, h1, e); }
+  { Epi e; e.R1 = h2; ln_ff(c, h1, M, tr.ln3, tr.cross_sp, HW, h2, t1, tr.ff1, tr.ff2, ffm, hs, e, qp); }
   // ---- temporal block (token order kept; only the attention gathers over frames)
   f16* xm = h0;   // h0 is dead
   f16* g1 = h1;   // h1 is dead
-  const bool f4 = fold_site(tr.tqkv, 0);
-  RowStat rs4; if (f4) rs4 = rowstat_alloc(c, M);
-  const bool ffu_in = ff_pair_fusable(c, M, tr.ffin1, tr.ffin2, Epi());     // the narrow level's fused feed-forward (with or without its in-kernel LayerNorm) keeps the site
-  if (!ffu_in && fold_site(tr.ffin1, UG_F_GEGLU)) {
-    // hs stays as it is (the final blend reads it): the stream with the frame embedding, xm, is written by the statistics-only launch
-    RowStat rs3 = rowstat_alloc(c, M);
-    layernorm_stats(c, hs, M, tr.ln_in, rs3.stat, tr.frame_emb, HW, xm);
-    { Epi e; e.flags = UG_F_GEGLU; e.ln_stat = rs3.stat; linear(c, xm, M, tr.ffin1, ffm, e); }
-    { Epi e; e.R1 = xm; if (f4) e.rs = &rs4; linear(c, ffm, M, tr.ffin2, g1, e); }
-  } else {
-    Epi e; e.R1 = xm; ln_ff(c, hs, M, tr.ln_in, tr.frame_emb, HW, xm, t1, tr.ffin1, tr.ffin2, ffm, g1, e, qp);
-  }
-  if (f4) { Epi e; e.ln_stat = rowstat_get(c, rs4, g1, M, tr.tln1); linear(c, g1, M, tr.tqkv, qkv, e); }
-  else ln_linear(c, g1, M, tr.tln1, t1, tr.tqkv, qkv, qp);
+  { Epi e; e.R1 = xm; ln_ff(c, hs, M, tr.ln_in, tr.frame_emb, HW, xm, t1, tr.ffin1, tr.ffin2, ffm, g1, e, qp); }
+  ln_linear(c, g1, M, tr.tln1, t1, tr.tqkv, qkv, qp);
   {
     TemporalAttnP p; p.Q = qkv; p.K = qkv + C; p.V = qkv + 2 * C; p.ld = 3 * C; p.O = ao; p.ldo = C;
     p.T = T; p.HW = HW; p.H = tr.heads; p.scale = 0.125f;
@@ -1183,15 +1063,10 @@ static f16* transformer_forward(Ctx& c, const Transformer& tr, const f16* x, int
   f16* g2 = h2;   // h2 is dead
   f16* g3 = xm;   // xm is dead
   f16* mix = g1;
-  const bool ffu_tm = ff_pair_fusable(c, M, tr.tff1, tr.tff2, Epi());     // the narrow level's fused feed-forward (with or without its in-kernel LayerNorm) keeps the site
   {
     Epi e; e.c0 = 1.f - tr.alpha; e.R1 = g3; e.c1 = 1.f - tr.alpha; e.R2 = hs; e.c2 = tr.alpha;
-    if (!ffu_tm && fold_site(tr.tff1, UG_F_GEGLU)) {
-      attn_out_ff(tr.to1, g1, tr.cross_tm, M, g2, g3, tr.tln3, tr.tff1, tr.tff2, mix, e);
-    } else {
-      { Epi e1; e1.R1 = g1; linear(c, ao, M, tr.to1, g2, e1); }
-      ln_ff(c, g2, M, tr.tln3, tr.cross_tm, M, g3, t1, tr.tff1, tr.tff2, ffm, mix, e, qp);
-    }
+    { Epi e1; e1.R1 = g1; linear(c, ao, M, tr.to1, g2, e1); }
+    ln_ff(c, g2, M, tr.tln3, tr.cross_tm, M, g3, t1, tr.tff1, tr.tff2, ffm, mix, e, qp);
   }
   { Epi e; e.R1 = x; linear(c, mix, M, tr.proj_out, out, e); }
   c.ws.release(mk);

@@ -56,7 +56,7 @@ template <int BM, int BN, int BK, int NST, int WMW, int WNW> struct GemmOcc {
 // loaders are byte movers, so an fp8 [rows][K] matrix is staged exactly like an fp16 [rows][K/2] one (the launcher halves K / lda /
 // ldw): a 128-byte LDS row is one 128-deep K step.  The block scales of a K step (one dword = 4 e8m0 per row) ride the same ring:
 // wave 0 / wave 1 fetch the A / W scale dwords of the tile's rows with one extra 1 KiB direct-to-LDS load each.
-template <int BM, int BN, int BK, int NST, int WMW, int WNW, bool CONV, bool UNI, bool BUFA = false, bool MX = false, bool ST = false, int EXT = 0>   // ST: statistics epilogue (GemmP::stat_part); EXT: round-5 epilogue extensions (tile_epilogue)
+template <int BM, int BN, int BK, int NST, int WMW, int WNW, bool CONV, bool UNI, bool BUFA = false, bool MX = false, bool ST = false>   // ST: statistics epilogue (GemmP::stat_part)
 __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>::wps)) void gemm_kernel(const GemmP p) {
   static_assert(!BUFA || !CONV || UNI, "buffer addressing needs the single-tap K tiles");
   static_assert(!MX || (!CONV && BK == 64 && BM <= 256 && BN <= 256), "MX path: dense, 128-byte K steps, <= 256 scale rows per operand");
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
     drain = true;
     const int tile = tw.first + ti * tw.step;
     { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn);
-      if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm); else tile_epilogue<MT, NT, WTM, WTN, EXT>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
+      if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm); else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
   }
 }
 
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
 // their fragment reads and MFMAs, so the matrix pipe runs the partner's K-step while the loader is queued on the
 // address path, and the loader's K-step afterwards.  Same LDS image, ring, barrier and MFMA order as gemm_kernel
 // (outputs are bit-identical).
-template <int BM, int BN, int NST, int WMW, int WNW, bool CONV, bool ST = false, int EXT = 0>   // ST: statistics epilogue (GemmP::stat_part); EXT: round-5 epilogue extensions
+template <int BM, int BN, int NST, int WMW, int WNW, bool CONV, bool ST = false>   // ST: statistics epilogue (GemmP::stat_part)
 __global__ __launch_bounds__(512, 2) void gemm_ldr_kernel(const GemmP p) {
   constexpr int BK = 64;
   static_assert(WMW * WNW == 8, "two waves per SIMD");
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ldr_kernel(const GemmP p) {
     const int tile = tw.first + (cp_ti++) * tw.step;
     drain = true;
     { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn);
-      if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm); else tile_epilogue<MT, NT, WTM, WTN, EXT>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
+      if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm); else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
   }
 }
 
@@ -672,7 +672,7 @@ static bool gemm_can_bufa(const GemmP& p, int BK, bool packed) {
 // publishes step i+1 and frees slot i % 3.  Only producers ever have loads in flight in the K loop, so the epilogue's
 // global traffic (consumers) needs no drain logic.  LDS image, W row permutation, MFMA chain order and epilogue are those
 // of gemm_kernel: outputs are bit-identical.
-template <int BM, int BN, int WMW, int WNW, bool CONV, bool ST = false, int EXT = 0>   // ST: GroupNorm statistics of the output from the epilogue (GemmP::stat_part); EXT: round-5 epilogue extensions
+template <int BM, int BN, int WMW, int WNW, bool CONV, bool ST = false>   // ST: GroupNorm statistics of the output from the epilogue (GemmP::stat_part)
 __global__ __launch_bounds__((WMW * WNW + 4) * 64, 3) void gemm_ws_kernel(const GemmP p) {
   constexpr int NST = 3;
   constexpr int BK = 64;
@@ -852,9 +852,9 @@ __global__ __launch_bounds__((WMW * WNW + 4) * 64, 3) void gemm_ws_kernel(const 
   int cp_ti = 0, cp_ks = 0, cp_slot = 0;
   // epilogue operands are fetched while K steps are still to come (EpiPre, kernels/gemm_common.h): column operands at the tile's first step, row
   // operands three steps before its last.  Knob 2097152 = off (A/B); split-K launches write raw partial sums and take no operands.
-  // Only the 192-row tiles have the registers (155 / 165 of the 168 three waves per SIMD leave; the 256-row tiles would spill 100 - 350 bytes per lane, the EXT forms 120 - 200).
-  constexpr bool PREK = (BM == 192) && EXT == 0;
-  EpiPre<MT, NT, EXT> pre;
+  // Only the 192-row tiles have the registers (155 / 165 of the 168 three waves per SIMD leave; the 256-row tiles would spill 100 - 350 bytes per lane).
+  constexpr bool PREK = (BM == 192);
+  EpiPre<MT, NT> pre;
   const bool do_pre = PREK && p.splitk <= 1 && !(p.tune_knobs & 2097152);
   const int prow_ks = nk > 3 ? nk - 3 : 0;
   __builtin_amdgcn_s_barrier();          // step 0 published
@@ -867,8 +867,8 @@ __global__ __launch_bounds__((WMW * WNW + 4) * 64, 3) void gemm_ws_kernel(const 
     UG_STAMP(0);
     if (PREK && do_pre && (cp_ks == 0 || cp_ks == prow_ks)) {
       int ptm, ptn; tile_coord_p(p, tw.first + cp_ti * tw.step, ntm, ntn, ptm, ptn);
-      if (cp_ks == 0) epi_pre_cols<MT, NT, WTM, WTN, EXT>(p, ptn * BN, wn, lane, pre);
-      if (cp_ks == prow_ks) epi_pre_rows<MT, NT, WTM, WTN, EXT>(p, ptm * BM, ptn * BN, wm, wn, lane, pre);
+      if (cp_ks == 0) epi_pre_cols<MT, NT, WTM, WTN>(p, ptn * BN, wn, lane, pre);
+      if (cp_ks == prow_ks) epi_pre_rows<MT, NT, WTM, WTN>(p, ptm * BM, ptn * BN, wm, wn, lane, pre);
     }
     const f16* Ab = smem + cp_slot * STAGE + (wm * WTM + l15) * BK;
     const f16* Bb = smem + cp_slot * STAGE + BM * BK + (wn * WTN + l15) * BK;
@@ -926,8 +926,8 @@ __global__ __launch_bounds__((WMW * WNW + 4) * 64, 3) void gemm_ws_kernel(const 
       const int tile = tw.first + (cp_ti++) * tw.step;
       { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn);
         if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm);
-        else if (PREK && do_pre) tile_epilogue<MT, NT, WTM, WTN, EXT, PREK>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off, &pre);
-        else tile_epilogue<MT, NT, WTM, WTN, EXT>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
+        else if (PREK && do_pre) tile_epilogue<MT, NT, WTM, WTN, PREK>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off, &pre);
+        else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all fragment reads of this slot are done before it is handed back
     UG_STAMP(2);
@@ -942,8 +942,6 @@ __global__ __launch_bounds__((WMW * WNW + 4) * 64, 3) void gemm_ws_kernel(const 
 #endif
   }
 }
-
-static inline bool gemm_wants_ext(const GemmP& p) { return p.ln_stat || p.row_part || p.bias2_rows > 0; }
 
 template <int BN, int WMW, int WNW, int BM = 256>
 static void launch_ws(const GemmP& p, int batch, hipStream_t s) {
@@ -974,16 +972,6 @@ static void launch_ws(const GemmP& p, int batch, hipStream_t s) {
       hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, WMW, WNW, true, true>), grid, dim3((WMW * WNW + 4) * 64), lds, s, p);
       return;
     } else UG_REQUIRE(false, "producer / consumer kernel: epilogue statistics on 128-column tiles only");
-  }
-  if (gemm_wants_ext(p)) {   // launch_gemm (gemm_epilogue_ext_ok): dense launches on the 192 x 128 tiles only
-    if constexpr (BM == 192 && BN == 128) {
-      UG_REQUIRE(!p.conv, "producer / consumer kernel: the round-5 epilogue extensions are dense only");
-      static bool attre[32] = {};
-      bool& ate = attre[ug_dev_slot()];
-      if (!ate) { UG_CHECK(hipFuncSetAttribute((const void*)gemm_ws_kernel<BM, BN, WMW, WNW, false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ate = true; }
-      hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, WMW, WNW, false, false, 1>), grid, dim3((WMW * WNW + 4) * 64), lds, s, p);
-      return;
-    } else UG_REQUIRE(false, "producer / consumer kernel: epilogue extensions on the 192 x 128 tiles only");
   }
   if (p.conv) hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, WMW, WNW, true>), grid, dim3((WMW * WNW + 4) * 64), lds, s, p);
   else hipLaunchKernelGGL((gemm_ws_kernel<BM, BN, WMW, WNW, false>), grid, dim3((WMW * WNW + 4) * 64), lds, s, p);
@@ -1020,16 +1008,6 @@ static void launch_ldr(const GemmP& p, int batch, hipStream_t s) {
       hipLaunchKernelGGL((gemm_ldr_kernel<BM, BN, NST, WMW, WNW, true, true>), grid, dim3(512), lds, s, p);
       return;
     } else UG_REQUIRE(false, "loader kernel: epilogue statistics on the 256 x 256 tile only");
-  }
-  if (gemm_wants_ext(p)) {   // launch_gemm (gemm_epilogue_ext_ok): dense launches on the 256 x 256 tile only, and of the extensions only the LayerNorm fold (EXT = 2)
-    if constexpr (BM == 256 && BN == 256) {
-      UG_REQUIRE(!p.conv && !p.row_part && p.bias2_rows <= 0, "loader kernel: dense launches, LayerNorm fold only");
-      static bool attre[32] = {};
-      bool& ate = attre[ug_dev_slot()];
-      if (!ate) { UG_CHECK(hipFuncSetAttribute((const void*)gemm_ldr_kernel<BM, BN, NST, WMW, WNW, false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ate = true; }
-      hipLaunchKernelGGL((gemm_ldr_kernel<BM, BN, NST, WMW, WNW, false, false, 2>), grid, dim3(512), lds, s, p);
-      return;
-    } else UG_REQUIRE(false, "loader kernel: epilogue extensions on the 256 x 256 tile only");
   }
   if (p.conv) hipLaunchKernelGGL((gemm_ldr_kernel<BM, BN, NST, WMW, WNW, true>), grid, dim3(512), lds, s, p);
   else hipLaunchKernelGGL((gemm_ldr_kernel<BM, BN, NST, WMW, WNW, false>), grid, dim3(512), lds, s, p);
@@ -1075,7 +1053,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue(const GemmP p) {
   }
 }
 
-template <int BM, int BN, int BK, int NST, int WMW, int WNW, bool CONV, bool UNI, bool BUFA = false, bool ST = false, int EXT = 0>
+template <int BM, int BN, int BK, int NST, int WMW, int WNW, bool CONV, bool UNI, bool BUFA = false, bool ST = false>
 static void launch_t(const GemmP& p, int batch, hipStream_t s) {
   const int ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
 #ifdef UG_GEMM_TRACE
@@ -1083,7 +1061,7 @@ static void launch_t(const GemmP& p, int batch, hipStream_t s) {
 #else
   const size_t lds = (size_t)NST * (BM + BN) * BK * sizeof(f16);
 #endif
-  auto kern = gemm_kernel<BM, BN, BK, NST, WMW, WNW, CONV, UNI, BUFA, false, ST, EXT>;
+  auto kern = gemm_kernel<BM, BN, BK, NST, WMW, WNW, CONV, UNI, BUFA, false, ST>;
   static bool attr[32] = {};
   bool& at = attr[ug_dev_slot()];
   if (!at) {
@@ -1123,10 +1101,6 @@ static void launch_mode(const GemmP& p, int batch, hipStream_t s) {
   } else {
     // dense: measured +4-6 % on the 8-wave tiles, -1..-4 % on the 4-wave 128x64 / 256x64 ones (profiles/r01_gemm_buffer_addressing.txt)
     const bool bufa = bufw && p.K % BK == 0 && (long)p.M * p.C0 * 2 < lim && (BM * BN >= 256 * 128 || (p.tune_knobs & 8));
-    if (gemm_wants_ext(p)) {   // launch_gemm (gemm_epilogue_ext_ok): of the symmetric kernel only the 3-stage 128 x 64 and the 128 x 128 tiles (configs 3 / 0: few-row launches), flat addressing
-      if constexpr ((BM == 128 && BN == 64 && NST == 3) || (BM == 128 && BN == 128 && NST == 2)) { launch_t<BM, BN, BK, NST, WMW, WNW, false, false, false, false, 1>(p, batch, s); return; }
-      else UG_REQUIRE(false, "symmetric kernel: epilogue extensions on the 3-stage 128 x 64 and the 128 x 128 tiles only");
-    }
     if (bufa) launch_t<BM, BN, BK, NST, WMW, WNW, false, false, true>(p, batch, s);
     else launch_t<BM, BN, BK, NST, WMW, WNW, false, false>(p, batch, s);
   }
@@ -1369,12 +1343,6 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
   }
   // (a former rule - four K slices of the 128x128 tile for the 12x16 level's concatenated 2560-channel convs, 880 TFLOP/s - is gone:
   // the 192-row tile fills the chip there without split-K, 236 vs 324 us = 1200 TFLOP/s)
-  // a launch that is to carry the round-5 epilogue extensions (LayerNorm fold, row partial sums, per-row bias2) needs a kernel instantiated with them
-  // (gemm_epilogue_ext_ok): the 192 x 128 producer / consumer tiles stand in for the 256-row ones (19200 x 5120 x 640 GEGLU: 137 vs 129 us in situ)
-  if (p.want_ext && !p.conv && batch == 1 && split == 1 && p.M > 2048 && gemm_can_bufa(p, 64, true)) {
-    const bool fits = cfg == 0 || cfg == 3 || cfg == 63 || cfg == 64 || (p.want_ext == 2 && cfg == 35);      // (want_ext 2 = the fold alone: the 256 x 256 loader tile has it)
-    if (!fits) cfg = (p.want_ext == 2 && cfg == 15) ? 35 : ((geglu || cfg == 54 || cfg == 62) ? 64 : 63);
-  }
   if ((p.tune_cfg_p1 - 1) >= 0 && !(geglu && (p.tune_cfg_p1 - 1) != 0 && (p.tune_cfg_p1 - 1) != 4 && (p.tune_cfg_p1 - 1) != 8 && (p.tune_cfg_p1 - 1) != 15 && (p.tune_cfg_p1 - 1) != 35 && (p.tune_cfg_p1 - 1) != 54 && (p.tune_cfg_p1 - 1) != 62 && (p.tune_cfg_p1 - 1) != 64)) cfg = (p.tune_cfg_p1 - 1);
   if ((p.tune_split_p1 - 1) >= 0) split = plain_epi ? std::max(1, (p.tune_split_p1 - 1)) : 1;
   *cfg_out = cfg; *split_out = split;
@@ -1427,36 +1395,10 @@ static bool cfg_geom(int cfg, int& bm, int& bn, int& wmw, int& wnw) {
   }
 }
 
-// Can THIS launch (the planner's tile for p, or the forced one) take the round-5 epilogue extensions - LayerNorm fold (GemmP::ln_stat), row partial sums
-// (GemmP::row_part), per-row-block bias2 (GemmP::bias2_rows)?  The engine asks before it commits a site to the folded form; launch_gemm requires it.
-// *slots = row_part slots the launch would write (column tiles x wave columns).
-bool gemm_epilogue_ext_ok(const GemmP& p0, int batch, int* slots) {
-  GemmP p = p0;
-  int cfg = p.cfg_p1 - 1, split = p.splitk;
-  if (cfg < 0 || split < 1) { int c2, s2; gemm_plan(p, batch, &c2, &s2); if (cfg < 0) cfg = c2; if (split < 1) split = s2; }
-  if (p.conv || batch != 1 || split != 1 || p.up_phase || (p.flags & UG_F_OUT_F32) || p.N % 64 != 0 || p.ldo % 8 != 0) return false;
-  if ((p.R1 && p.ldr1 % 8 != 0) || (p.R2 && p.ldr2 % 8 != 0)) return false;
-  if (!(p.tune_knobs & 65536) && (p.tune_cfg_p1 - 1) < 0 && gemm_stream_supported(p, batch)) return false;   // the streaming kernel takes it (its own epilogue)
-  int bm, bn, wmw, wnw;
-  if (!cfg_geom(cfg, bm, bn, wmw, wnw)) return false;
-  // the kernels instantiated with the extensions: the 3-stage 128 x 64 and the 128 x 128 symmetric tiles (3 / 0) and the dense 192 x 128 producer / consumer
-  // kernels (63 / 64; only in their buffer-addressed form - launch_cfg falls back to the symmetric kernel otherwise).  The 256 x 256 loader tile (35) has the
-  // LayerNorm fold alone (EXT = 2: one register per row; with the row sums / per-row bias2 code it spills 450 bytes per lane) - GemmP::want_ext steers the planner.
-  const bool pk = (cfg == 63 || cfg == 64) && gemm_can_bufa(p, 64, true);
-  const bool ldr_fold = cfg == 35 && gemm_can_bufa(p, 64, true) && !p.row_part && p.bias2_rows <= 0;     // the 256 x 256 loader tile: the LayerNorm fold alone
-  if (!(cfg == 3 || cfg == 0 || pk || ldr_fold)) return false;
-  // slot index in tile_epilogue = global wave-column index (n0 / WTN + wn); a wave column entirely beyond N never writes its slot, so only the in-range
-  // ones count (N % 64 == 0 and WTN = bn / wnw in {32, 64} make the division exact) - k_rowstat_finalize sums every slot it is told about
-  if (slots) *slots = p.N / (bn / wnw);
-  return true;
-}
-
-void launch_gemm(const GemmP& p0, int batch, hipStream_t s, int* stat_rb, int* row_slots) {
+void launch_gemm(const GemmP& p0, int batch, hipStream_t s, int* stat_rb) {
   GemmP p = p0;
   if (stat_rb) *stat_rb = 0;
   if (!stat_rb) p.stat_part = nullptr;
-  if (row_slots) *row_slots = 0;
-  if (!row_slots) p.row_part = nullptr;
   if (p.tune_knobs & 2) p.flags |= UG_F_NOXCD;
   if (p.tune_knobs & 128) p.flags |= UG_F_XCDROUND;
   if (p.tune_knobs & 16) p.flags |= UG_F_PRIO;
@@ -1566,16 +1508,6 @@ void launch_gemm(const GemmP& p0, int batch, hipStream_t s, int* stat_rb, int* r
     static const bool sdbg = getenv("UG_STAT_DEBUG") != nullptr;
     if (sdbg) fprintf(stderr, "[stat] M %d N %d K %d conv %d kt %d hw %d cfg %d split %d -> rb %d\n", p.M, p.N, p.K, p.conv, p.kt, p.stat_hw, cfg, split, ok ? wtm : 0);
     if (ok) *stat_rb = wtm; else p.stat_part = nullptr;
-  }
-  if (p.ln_stat || p.row_part || p.bias2_rows) {
-    int slots = 0;
-    GemmP q = p; q.cfg_p1 = cfg + 1; q.splitk = split;
-    const bool ok = gemm_epilogue_ext_ok(q, batch, &slots) && cfg != 80 && !(cfg >= 70 && cfg <= 73);
-    if (p.ln_stat) UG_REQUIRE(ok && !p.bias && p.ln_s && p.ln_bias, "LayerNorm fold: dense single-pass launch on a tile_epilogue kernel, N % 64 == 0, bias folded into ln_bias");
-    if (p.bias2_rows) UG_REQUIRE(ok && p.bias2 && !(p.flags & UG_F_GEGLU), "per-row bias2: dense single-pass launch on a tile_epilogue kernel");
-    if (p.row_part) {
-      if (ok && !(p.flags & UG_F_GEGLU)) *row_slots = slots; else p.row_part = nullptr;
-    }
   }
   launch_cfg(cfg, p, batch, s);
   if (split > 1) {

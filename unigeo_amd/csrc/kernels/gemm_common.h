@@ -86,53 +86,32 @@ __device__ __forceinline__ TileWalk tile_walk(int flags, int ntiles, int nwg, in
   return t;
 }
 
-// x summed over the four lanes l, l + 16, l + 32, l + 48 (one MFMA output row's four column groups), in every lane: two gfx950 lane-swap instructions
-// (v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of the second; v_permlane32_swap: upper half <-> lower half) - VALU only; as
-// ds_bpermute shuffles the four exchanges per output row were four dependent LDS round trips (+4 us on the 19200 x 640 x 640 projection's 28).
-__device__ __forceinline__ float quad_rows_sum(float x) {
-  // Inline asm, two copies of the value in two registers: through __builtin_amdgcn_permlane16_swap hipcc (ROCm 7.2) either emits `v_permlane16_swap v1, v1`
-  // (same value twice: a register swapped with itself) or, with the copy hidden behind an asm barrier, adds result[0] to itself - both give 4 x instead of the
-  // sum (tools/microbench/permlane_probe.hip).  s_nop: the VALU-write -> lane-swap-read hazard the compiler would have covered for its own instruction.
-  float a = x, b = x;
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-  float c = a + b, d = c;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(c), "+v"(d));
-  return c + d;
-}
-
 template <int N> struct HVec;
 template <> struct HVec<8> { typedef f16x8 type; };
 template <> struct HVec<4> { typedef f16x4 type; };
 
 // Epilogue operands fetched AHEAD of the epilogue (round 5, the producer / consumer kernel): a tile of a short-K layer lasts 4 - 8 us and every dependent round
-// trip to L2 / HBM at the start of its epilogue (bias; the residual rows; for the LayerNorm fold ln_s / ln_bias / the row statistics) keeps the CU's matrix
-// pipes idle for 1 - 2 us of it - measured: the fold's three extra loads cost the 19200 x 1920 x 640 projection 13.7 us of 62 (profiles/r05_epilogue_prefetch.txt).
+// trip to L2 / HBM at the start of its epilogue (bias; the residual rows) keeps the CU's matrix pipes idle for 1 - 2 us of it (profiles/r05_ln_fold_and_epilogue_prefetch.txt).
 // The compute waves issue these loads into registers while K steps are still to come - the column operands at the tile's first step, the row operands three steps
 // before its last - and the epilogue finds them landed.  Raw loaded vectors only: any arithmetic on them would pull the wait forward.
-template <int MT, int NT, int EXT> struct EpiPre {
+template <int MT, int NT> struct EpiPre {
   static constexpr int WID = 4 * NT, CH = (WID % 8 == 0) ? 8 : 4, NV = WID / CH;
   typedef typename HVec<CH>::type hvec;
   hvec b1[NV], b2[NV];                                   // bias, bias2 (one vector for all rows) of the lane's columns
-  hvec r1[EXT ? 1 : MT][EXT ? 1 : NV];                   // R1 rows (fp16, not with GEGLU); the EXT instantiations keep their in-epilogue loads (registers)
-  f32x4 lb[EXT ? WID / 4 : 1];                           // LayerNorm fold: ln_bias
-  float2 st[EXT ? MT : 1];                               // ... (mean, rstd) of the lane's rows
+  hvec r1[MT][NV];                                       // R1 rows (fp16, not with GEGLU)
 };
-template <int MT, int NT, int WTM, int WTN, int EXT>
-__device__ __forceinline__ void epi_pre_cols(const GemmP& p, int n0, int wn, int lane, EpiPre<MT, NT, EXT>& pre) {
-  typedef EpiPre<MT, NT, EXT> P;
+template <int MT, int NT, int WTM, int WTN>
+__device__ __forceinline__ void epi_pre_cols(const GemmP& p, int n0, int wn, int lane, EpiPre<MT, NT>& pre) {
+  typedef EpiPre<MT, NT> P;
   typedef typename P::hvec hvec;
   const int g = lane >> 4;
   const int nb = n0 + wn * WTN + g * P::WID;
   if (nb + P::WID > p.N) return;                        // tile_epilogue takes its scalar path for this lane
-  if (EXT && p.ln_stat) {
-#pragma unroll
-    for (int e = 0; e < P::WID; e += 4) pre.lb[e / 4] = *(const f32x4*)(p.ln_bias + nb + e);
-  }
   if (p.bias) {
 #pragma unroll
     for (int v = 0; v < P::NV; ++v) pre.b1[v] = *(const hvec*)(p.bias + nb + v * P::CH);
   }
-  if (p.bias2 && !(EXT == 1 && p.bias2_rows > 0)) {
+  if (p.bias2) {
 #pragma unroll
     for (int v = 0; v < P::NV; ++v) pre.b2[v] = *(const hvec*)(p.bias2 + nb + v * P::CH);
   }
@@ -141,27 +120,20 @@ __device__ __forceinline__ void epi_pre_cols(const GemmP& p, int n0, int wn, int
 __device__ __forceinline__ bool epi_pre_r1_ok(const GemmP& p) {
   return p.R1 && !(p.flags & (UG_F_R1_F32 | UG_F_GEGLU)) && (p.ldo & 7) == 0 && (p.ldr1 & 7) == 0 && (!p.R2 || (p.ldr2 & 7) == 0);
 }
-template <int MT, int NT, int WTM, int WTN, int EXT>
-__device__ __forceinline__ void epi_pre_rows(const GemmP& p, int m0, int n0, int wm, int wn, int lane, EpiPre<MT, NT, EXT>& pre) {
-  typedef EpiPre<MT, NT, EXT> P;
+template <int MT, int NT, int WTM, int WTN>
+__device__ __forceinline__ void epi_pre_rows(const GemmP& p, int m0, int n0, int wm, int wn, int lane, EpiPre<MT, NT>& pre) {
+  typedef EpiPre<MT, NT> P;
   typedef typename P::hvec hvec;
   const int l15 = lane & 15, g = lane >> 4;
   const int nb = n0 + wn * WTN + g * P::WID;
   if (nb + P::WID > p.N) return;
-  if constexpr (EXT) {
-    if (p.ln_stat) {
+  if (epi_pre_r1_ok(p)) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) { const int m = m0 + wm * WTM + i * 16 + l15; pre.st[i] = m < p.M ? p.ln_stat[m] : make_float2(0.f, 0.f); }
-    }
-  } else {
-    if (epi_pre_r1_ok(p)) {
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * WTM + i * 16 + l15;
+      if (m < p.M) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int m = m0 + wm * WTM + i * 16 + l15;
-        if (m < p.M) {
-#pragma unroll
-          for (int v = 0; v < P::NV; ++v) pre.r1[i][v] = *(const hvec*)(p.R1 + (long)m * p.ldr1 + nb + v * P::CH);
-        }
+        for (int v = 0; v < P::NV; ++v) pre.r1[i][v] = *(const hvec*)(p.R1 + (long)m * p.ldr1 + nb + v * P::CH);
       }
     }
   }
@@ -169,13 +141,13 @@ __device__ __forceinline__ void epi_pre_rows(const GemmP& p, int m0, int n0, int
 
 // Per-tile epilogue shared by the GEMM kernels: the lane holds WID = 4*NT contiguous columns of rows
 // m0 + wm*WTM + i*16 + (lane & 15).  Clears the accumulators for the next tile.
-// EXT (round 5; 0 = none, 1 = all three below, 2 = the LayerNorm fold alone - the 256 x 256 loader tile, which has no register to spare; compile-time so that the other instantiations keep their register allocation - as run-time branches these cost every GEMM kernel ~20 VGPRs,
-// an occupancy step on three tiles and 100 bytes of scratch in the 256 x 256 ones): LayerNorm fold (GemmP::ln_stat), row partial sums of the output
-// (GemmP::row_part), per-row-block bias2 (GemmP::bias2_rows).  launch_gemm sends a launch to an EXT instantiation only when one of the three is set.
-// PRE: the operands above come from `pre` (filled by epi_pre_cols / epi_pre_rows for THIS tile) instead of being loaded here.
-template <int MT, int NT, int WTM, int WTN, int EXT = 0, bool PRE = false>
+// Anything new in here has to be a COMPILE-TIME variant instantiated only where it is used: run-time branches in this function cost every GEMM kernel that
+// inlines it its register allocation (round 5: the LayerNorm-fold extensions as run-time branches, ~20 VGPRs and an occupancy step; round 6: a split-K
+// fix-up path that was never taken, 960 -> 1284 ms per clip - profiles/r06_split_k_ticket_fixup_rejected.txt).
+// PRE: bias / bias2 / the R1 rows come from `pre` (filled by epi_pre_cols / epi_pre_rows for THIS tile) instead of being loaded here.
+template <int MT, int NT, int WTM, int WTN, bool PRE = false>
 __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wm, int wn, int lane,
-                                              long out_off, const EpiPre<MT, NT, EXT>* pre = nullptr) {
+                                              long out_off, const EpiPre<MT, NT>* pre = nullptr) {
   constexpr int WID = 4 * NT;
   constexpr int CH = (WID % 8 == 0) ? 8 : 4;   // vector width of the epilogue's loads / stores (WID = 20: 80-column wave tiles)
   typedef typename HVec<CH>::type hvec;
@@ -203,33 +175,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][N
   const bool full = (nb + WID <= p.N);
   const bool vec = full && ((p.ldo & 7) == 0) && (!p.R1 || (p.ldr1 & 7) == 0) &&
                    (!p.R2 || (p.ldr2 & 7) == 0) && (OW % CH == 0);
-  const bool lnf = EXT != 0 && p.ln_stat != nullptr;   // LayerNorm folded into this GEMM (GemmP::ln_stat): whole column runs only (launch_gemm: N % 64 == 0)
   float bv[WID];
 #pragma unroll
   for (int e = 0; e < WID; ++e) bv[e] = 0.f;
-  float rsv[EXT ? MT : 1];                        // the fold's row scales rstd[m]
-  if constexpr (EXT != 0) {
-    // The fold: the weights are centred at bind time (W'' = gamma o W minus its row mean, k_fold_ln_weights), so acc = x W''^T = (x - mean) (gamma o W)^T
-    // already - what is left for the epilogue is the row scale rstd[m] (applied where the bias is added, below) and the folded bias ln_bias (fp32) in place
-    // of bias.  One register per row: a mean[m] * s[n] correction would need a second per-column array - 476 bytes of scratch per lane on the 256 x 256 tile.
-#pragma unroll
-    for (int i = 0; i < MT; ++i) rsv[i] = 1.f;
-    if (lnf && full) {
-#pragma unroll
-      for (int e = 0; e < WID; e += 4) {
-        f32x4 lb;
-        if constexpr (PRE) lb = pre->lb[e / 4]; else lb = *(const f32x4*)(p.ln_bias + nb + e);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bv[e + q] = lb[q];
-      }
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        if constexpr (PRE) rsv[i] = pre->st[i].y;
-        else rsv[i] = p.ln_stat[min(m0 + wm * WTM + i * 16 + l15, p.M - 1)].y;     // (unconditional, clamped: a per-row `if (m < M)` makes MT dependent loads of them)
-      }
-    }
-  }
-  const bool b2row = EXT == 1 && p.bias2_rows > 0;     // bias2 is a per-row-block vector (added per row below)
   if (full) {
     if (p.bias) {
 #pragma unroll
@@ -240,7 +188,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][N
         for (int q = 0; q < CH; ++q) bv[e + q] += (float)b[q];
       }
     }
-    if (p.bias2 && !b2row) {
+    if (p.bias2) {
 #pragma unroll
       for (int e = 0; e < WID; e += CH) {
         hvec b;
@@ -274,24 +222,11 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][N
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if constexpr (EXT != 0) v[j * 4 + r] = acc[i][j][r] * rsv[i] + bv[j * 4 + r];
-        else v[j * 4 + r] = acc[i][j][r] + bv[j * 4 + r];
+        v[j * 4 + r] = acc[i][j][r] + bv[j * 4 + r];
       }
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (m >= p.M) continue;
-    if constexpr (EXT == 1) {
-      if (b2row && full) {
-        const f16* b2 = p.bias2 + (long)(m / p.bias2_rows) * p.N + nb;
-#pragma unroll
-        for (int e = 0; e < WID; e += CH) {
-          const hvec b = *(const hvec*)(b2 + e);
-#pragma unroll
-          for (int q = 0; q < CH; ++q) v[e + q] += (float)b[q];
-        }
-      }
-    }
-    float rsum = 0.f, rsq = 0.f;               // GemmP::row_part: sum / sum of squares of the fp16 values this lane stores for row m
     if (geglu) {
       if (WID == 16) {
 #pragma unroll
@@ -314,7 +249,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][N
             for (int q = 0; q < CH; q += 4) { const f32x4 r = *(const f32x4*)(R + q); o[q] += p.c1 * r[0]; o[q + 1] += p.c1 * r[1]; o[q + 2] += p.c1 * r[2]; o[q + 3] += p.c1 * r[3]; }
           } else {
             hvec r;
-            if constexpr (PRE && !EXT) { if (!geglu) r = pre->r1[i][e / CH]; else r = *(const hvec*)(p.R1 + (long)m * p.ldr1 + ob + e); }
+            if constexpr (PRE) { if (!geglu) r = pre->r1[i][e / CH]; else r = *(const hvec*)(p.R1 + (long)m * p.ldr1 + ob + e); }
             else r = *(const hvec*)(p.R1 + (long)m * p.ldr1 + ob + e);
 #pragma unroll
             for (int q = 0; q < CH; ++q) o[q] += p.c1 * (float)r[q];
@@ -341,17 +276,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][N
 #pragma unroll
           for (int q = 0; q < CH; ++q) h[q] = (f16)o[q];
           *(hvec*)((f16*)p.Out + out_off + orow * p.ldo + ob + e) = h;
-          if constexpr (EXT == 1) {
-            if (p.row_part) {
-#pragma unroll
-              for (int q = 0; q < CH; ++q) { const float f = (float)h[q]; rsum += f; rsq += f * f; }
-            }
-          }
         }
-      }
-      if (EXT == 1 && p.row_part) {   // launch_gemm: only launches whose every in-range lane takes this fp16 vector path; the four lanes l15 + 16 g hold one row's 4 * WID columns of this wave
-        rsum = quad_rows_sum(rsum); rsq = quad_rows_sum(rsq);
-        if (g == 0) p.row_part[(long)(n0 / WTN + wn) * p.M + m] = make_float2(rsum, rsq);
       }
     } else {
 #pragma unroll

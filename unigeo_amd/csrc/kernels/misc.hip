@@ -546,37 +546,3 @@ void launch_normals(const float* depth, const float* K33, float* normals, int T,
   hipLaunchKernelGGL(k_normals, gs_grid((long)T * H * W), dim3(256), 0, s, depth, K33, normals, T, H, W);
 }
 
-// LayerNorm folded into the linear layer that consumes it (bind time, once): one wave per output row n.
-//   LayerNorm(x) W^T + bias = rstd * ((x - mean 1) (gamma o W)^T) + (bias + W beta),   and   (x - mean 1) V^T = x (V - rowmean(V) 1^T)^T   for any V
-// (subtracting a row's mean from x is the projection P = I - 11^T / K, which is symmetric: x P V^T = x (V P)^T).  So with the CENTRED weights
-//   Wf[n][k] = fp16(W[n][k] gamma[k] - (1/K) sum_j W[n][j] gamma[j])
-// the GEMM on the raw rows already produces (x - mean) (gamma o W)^T, and its epilogue only scales row m by rstd[m] and adds bf[n] = bias[n] + sum_k beta[k] W[n][k].
-// s_out[n] = sum_k float(Wf[n][k]): what the fp16 rounding leaves of the row sum (exactly 0 without it) - the residual coupling to the row mean, reported for
-// the tests (|s_out| ~ 1e-3: a row mean of 10 standard deviations moves an output by 1e-2 of ITS standard deviation).
-__global__ __launch_bounds__(256) void k_fold_ln_weights(const f16* W, const f16* bias, const f16* gamma, const f16* beta, f16* Wf, float* s_out, float* b_out, int N, int K) {
-  const int lane = threadIdx.x & 63;
-  const long n = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;
-  float s1 = 0.f, s2 = 0.f;
-  for (int k = lane; k < K; k += 64) {
-    const float w = (float)W[n * K + k];
-    s1 += w * (float)gamma[k];
-    s2 += (float)beta[k] * w;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-  const float mu = s1 / K;
-  float s3 = 0.f;
-  for (int k = lane; k < K; k += 64) {
-    const f16 wf = (f16)((float)W[n * K + k] * (float)gamma[k] - mu);
-    Wf[n * K + k] = wf;
-    s3 += (float)wf;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s3 += __shfl_xor(s3, o);
-  if (lane == 0) { s_out[n] = s3; b_out[n] = s2 + (bias ? (float)bias[n] : 0.f); }
-}
-void launch_fold_ln_weights(const f16* W, const f16* bias, const f16* gamma, const f16* beta, f16* Wf, float* s_out, float* b_out, int N, int K, hipStream_t s) {
-  hipLaunchKernelGGL(k_fold_ln_weights, dim3(cdiv(N, 4)), dim3(256), 0, s, W, bias, gamma, beta, Wf, s_out, b_out, N, K);
-  UG_CHECK(hipGetLastError());
-}

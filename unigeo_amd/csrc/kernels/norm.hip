@@ -662,10 +662,6 @@ __global__ __launch_bounds__(256) void ln_kernel(const LayerNormP p) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
   const float rstd = rsqrtf(var / p.C + p.eps);
-  if (p.stat_out) {   // statistics-only form: the consumer GEMM applies the normalisation in its epilogue (GemmP::ln_stat)
-    if (lane == 0) p.stat_out[row] = make_float2(mean, rstd);
-    return;
-  }
 #pragma unroll
   for (int k = 0; k < VPL; ++k) {
     const int v = lane + k * 64;
@@ -713,36 +709,3 @@ void launch_layernorm(const LayerNormP& p, hipStream_t s) {
   UG_CHECK(hipGetLastError());
 }
 
-// (mean, rstd)[m] from the per-slot row sums a producing GEMM's epilogue wrote (GemmP::row_part, [slots][M]): the sums are those of the fp16 values stored,
-// so mean is exact to fp32 summation; var = E[x^2] - mean^2 is formed in double (the partial sums are fp32: with |mean| >> std the cancellation costs bits of
-// the sums themselves - fine for the residual streams of this network, where |mean| <~ std; the statistics-only LayerNorm launch is the exact alternative).
-// 256 threads = 64 rows x 4 slot groups (thread (r, q) takes slots q, q + 4, ... - at most 10 of the 40 a producer can write, all loads issued before the
-// first add), combined through LDS: as one thread per row walking the slots in a loop the launch was 20 - 40 dependent L2 round trips long (12 us in the clip).
-__global__ __launch_bounds__(256) void k_rowstat_finalize(const float2* part, int slots, long M, int C, float eps, float2* stat) {
-  __shared__ double2 red[4][64];
-  const int r = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const long m = (long)blockIdx.x * 64 + r;
-  float2 v[10];
-#pragma unroll
-  for (int j = 0; j < 10; ++j) {
-    const int sl = q + 4 * j;
-    v[j] = (m < M && sl < slots) ? part[(long)sl * M + m] : make_float2(0.f, 0.f);
-  }
-  double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-  for (int j = 0; j < 10; ++j) { s1 += (double)v[j].x; s2 += (double)v[j].y; }
-  red[q][r] = make_double2(s1, s2);
-  __syncthreads();
-  if (q == 0 && m < M) {
-#pragma unroll
-    for (int k = 1; k < 4; ++k) { s1 += red[k][r].x; s2 += red[k][r].y; }
-    const double mean = s1 / C;
-    const double var = fmax(s2 / C - mean * mean, 0.0);
-    stat[m] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
-  }
-}
-void launch_rowstat_finalize(const float2* part, int slots, long M, int C, float eps, float2* stat, hipStream_t s) {
-  UG_REQUIRE(slots > 0 && slots <= 40 && M > 0, "rowstat_finalize: 1 .. 40 slots");
-  hipLaunchKernelGGL(k_rowstat_finalize, dim3(cdiv(M, 64)), dim3(256), 0, s, part, slots, M, C, eps, stat);
-  UG_CHECK(hipGetLastError());
-}

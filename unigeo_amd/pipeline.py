@@ -46,7 +46,7 @@ class DepthCrafterPipelineHIP:
         nbytes = sum(int(np.prod(a.shape)) * 2 for s in (unet_state, vae_state, clip_state) for a in s.values())
         eng = Engine(device_id,
                      workspace_bytes if workspace_bytes is not None else (24 << 30),
-                     persist_bytes if persist_bytes is not None else int(nbytes * 1.35) + (256 << 20))   # incl. room for the LayerNorm-folded copies of qkv / GEGLU projections made by set_ln_fold (round 5)
+                     persist_bytes if persist_bytes is not None else int(nbytes * 1.35) + (256 << 20))   # weights + re-laid convolution / fused / fp8 copies made at bind time
         eng.load_state("unet.", unet_state); eng.bind_unet(u)
         eng.load_state("vae.", vae_state); eng.bind_vae(v)
         eng.load_state("clip.", clip_state); eng.bind_clip(c)
