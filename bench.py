@@ -552,7 +552,7 @@ def main():
             # also carries the algorithmic bytes of ITS OWN step mix; the file is cited by hash
             try:
                 import hashlib
-                pf = next(f for f in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic_gemm.json") for r in (5, 4, 3)) if os.path.exists(f))
+                pf = next(f for f in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic_gemm.json") for r in (6, 5, 4, 3)) if os.path.exists(f))
                 raw = open(pf, "rb").read()
                 pm = json.loads(raw)
                 res["roofline"]["traffic"] = round(pm["hbm_bytes_per_launch"])
