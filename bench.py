@@ -21,6 +21,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import unigeo_amd  # noqa: E402,F401  (first: sets HIP_FORCE_DEV_KERNARG=1 before torch or the engine make their first HIP call - unigeo_amd/__init__.py)
 
 # algorithmic work, SURVEY.md 8(d) / BASELINE.md 3 (MAC = 2 FLOP), T=25, 384x512
 TFLOP_UNET, TFLOP_VAE_ENC, TFLOP_VAE_DEC, TFLOP_CLIP = 23.21, 20.78, 56.89, 8.38
@@ -570,6 +571,7 @@ def main():
             if full:
                 clip_tflop = a.denoise_steps * TFLOP_UNET + TFLOP_VAE_ENC + TFLOP_VAE_DEC + TFLOP_CLIP
                 res["pipeline_tflops"] = round(clip_tflop / (ms * 1e-3), 1)
+        res["runtime_switches"] = {k: v[1] for k, v in unigeo_amd.runtime_switches().items()}     # HIP runtime configuration this process ran with (unigeo_amd/__init__.py)
         res["workspace_peak_gb"] = round(eng.workspace_peak() / 2 ** 30, 2)      # the headline workload's arena high-water mark (before the side runs below)
         if not a.no_extras:
             # The reference's own boundary is host to host (model/depthcrafter.py:80-90 takes numpy frames and returns numpy): upload of frames + noise,
