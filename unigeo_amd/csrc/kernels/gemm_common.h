@@ -16,7 +16,7 @@ __device__ __forceinline__ float erf_as(float x) {
   return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   // hardware reciprocal, as kernels/norm.hip
 
 // GEGLU on two (value, gate) pairs in packed fp32 (v_pk_fma/mul/add_f32 issue two lanes' worth per instruction):
 //   h * g * Phi(g),  Phi(g) = 1/2 + sign(g) (1/2 - erfc(|g|/sqrt2)/2),  erfc by the same Abramowitz-Stegun 7.1.26 form as

@@ -370,7 +370,7 @@ void launch_euler_step(const f16* v, f16* lat, long n, float sigma, float sigma_
 }
 
 __global__ void k_silu(const f16* in, f16* out, long n) {
-  GS_LOOP(i, n) { const float x = (float)in[i]; out[i] = (f16)(x / (1.0f + __expf(-x))); }
+  GS_LOOP(i, n) { const float x = (float)in[i]; out[i] = (f16)(x * __builtin_amdgcn_rcpf(1.0f + __expf(-x))); }
 }
 void launch_silu_f16(const f16* in, f16* out, long n, hipStream_t s) {
   hipLaunchKernelGGL(k_silu, gs_grid(n), dim3(256), 0, s, in, out, n);

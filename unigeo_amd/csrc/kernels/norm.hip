@@ -14,11 +14,14 @@
 #include "../common.h"
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #define GN_THREADS 256
 #define GN_MAXV 3  // vectors per thread => C <= 3*256*8
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// SiLU with the hardware reciprocal (1 ulp) instead of the correctly rounded fp32 division hipcc emits for `/` (14 instructions per element, which made the apply
+// passes VALU-bound: round 6).  Every GroupNorm form and the GEMM epilogue share this definition (gemm_common.h carries the same one).
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 struct GnGeom { int nvec, tpr, rpi, vpt; };
 // nvec 8-channel vectors per row; tpr threads cooperate on a row, rpi rows per iteration,
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(64) void gn_finalize_pool(const GroupNormP p, const
 }
 
 // phase 3 for workgroup (chunk, t): y = silu(x * a[c] + b[c]); coef(c, a, b) supplies the per-channel scale / shift
-template <typename F>
+template <bool SILU, typename F>
 __device__ __forceinline__ void gn_apply_body(const GroupNormP& p, int t, int chunk, int rows_per_chunk, F coef) {
   const int C = p.C0 + p.C1;
   const GnGeom gg = gn_geom(C);
@@ -254,7 +257,7 @@ __device__ __forceinline__ void gn_apply_body(const GroupNormP& p, int t, int ch
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float f = (float)x[u][e] * a[0][e] + b[0][e];
-          if (p.silu) f = silu_f(f);
+          if (SILU) f = silu_f(f);
           y[e] = (f16)f;
         }
         *(f16x8*)(p.Y + ((long)t * p.HW + r + u * gg.rpi) * C + c) = y;
@@ -266,7 +269,7 @@ __device__ __forceinline__ void gn_apply_body(const GroupNormP& p, int t, int ch
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float f = (float)x[e] * a[0][e] + b[0][e];
-        if (p.silu) f = silu_f(f);
+        if (SILU) f = silu_f(f);
         y[e] = (f16)f;
       }
       *(f16x8*)(p.Y + ((long)t * p.HW + r) * C + c) = y;
@@ -284,7 +287,7 @@ __device__ __forceinline__ void gn_apply_body(const GroupNormP& p, int t, int ch
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float f = (float)x[e] * a[k][e] + b[k][e];
-          if (p.silu) f = silu_f(f);
+          if (SILU) f = silu_f(f);
           y[e] = (f16)f;
         }
         *(f16x8*)(p.Y + m * C + v * 8) = y;
@@ -293,9 +296,14 @@ __device__ __forceinline__ void gn_apply_body(const GroupNormP& p, int t, int ch
   }
 }
 
+template <bool SILU>   // compile time: a run-time flag is a branch per ELEMENT in the unrolled loops
 __global__ __launch_bounds__(GN_THREADS) void gn_apply(const GroupNormP p, int rows_per_chunk, const float* ab) {
   const int C = p.C0 + p.C1, t = blockIdx.y;
-  gn_apply_body(p, t, blockIdx.x, rows_per_chunk, [&](int c, float& a, float& b) { a = ab[((long)t * C + c) * 2 + 0]; b = ab[((long)t * C + c) * 2 + 1]; });
+  gn_apply_body<SILU>(p, t, blockIdx.x, rows_per_chunk, [&](int c, float& a, float& b) { a = ab[((long)t * C + c) * 2 + 0]; b = ab[((long)t * C + c) * 2 + 1]; });
+}
+static void launch_gn_apply(const GroupNormP& p, int nchunk, int rpc, const float* ab, hipStream_t s) {
+  if (p.silu) hipLaunchKernelGGL(gn_apply<true>, dim3(nchunk, p.T), dim3(GN_THREADS), 0, s, p, rpc, ab);
+  else hipLaunchKernelGGL(gn_apply<false>, dim3(nchunk, p.T), dim3(GN_THREADS), 0, s, p, rpc, ab);
 }
 
 // rows per chunk: enough workgroups (T * nchunk >= ~1024) to fill 256 CUs several times over, but at
@@ -348,9 +356,8 @@ __global__ __launch_bounds__(256) void gn_small(const GroupNormP p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float a = rstd * (float)ga[e];
-      float f = (float)x[e] * a + ((float)be[e] - mean * a);
-      if (p.silu) f = silu_f(f);
-      y[e] = (f16)f;
+      const float f = (float)x[e] * a + ((float)be[e] - mean * a);
+      y[e] = (f16)(p.silu ? silu_f(f) : f);
     }
     *(f16x4*)(p.Y + (row0 + r) * C + c) = y;
   }
@@ -451,17 +458,20 @@ __global__ __launch_bounds__(NT) void gn_slab(const GroupNormP p) {
   float a[4], b[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) { a[e] = rstd * (float)ga[e]; b[e] = (float)be[e] - mean * a[e]; }
+  auto out = [&](auto SILU) {      // the flag is uniform: one branch per launch, not one per element of the unrolled loop
 #pragma unroll
-  for (int k = 0; k < VMAX; ++k) {
-    f16x4 y;
+    for (int k = 0; k < VMAX; ++k) {
+      f16x4 y;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float f = (float)x[k][e] * a[e] + b[e];
-      if (p.silu) f = silu_f(f);
-      y[e] = (f16)f;
+      for (int e = 0; e < 4; ++e) {
+        float f = (float)x[k][e] * a[e] + b[e];
+        if (decltype(SILU)::value) f = silu_f(f);
+        y[e] = (f16)f;
+      }
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, y), rY, act ? (int)(yoff + k * stepy) : (int)OOB, 0, 0);   // rows >= R: dropped
     }
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, y), rY, act ? (int)(yoff + k * stepy) : (int)OOB, 0, 0);   // rows >= R: dropped
-  }
+  };
+  if (p.silu) out(std::true_type{}); else out(std::false_type{});
 }
 
 template <int MODE>
@@ -588,7 +598,7 @@ bool launch_groupnorm(const GroupNormP& p, hipStream_t s) {
     } else {
       hipLaunchKernelGGL(gn_finalize_cols<false>, dim3(p.G, p.temporal ? 1 : p.T), dim3(nitem > 2048 ? 1024 : 256), 0, s, p, ab, (double2*)nullptr);
     }
-    hipLaunchKernelGGL(gn_apply, dim3(nchunk, p.T), dim3(GN_THREADS), 0, s, p, rpc, (const float*)ab);
+    launch_gn_apply(p, nchunk, rpc, (const float*)ab, s);
     UG_CHECK(hipGetLastError());
     return true;
   }
@@ -608,7 +618,7 @@ bool launch_groupnorm(const GroupNormP& p, hipStream_t s) {
     hipLaunchKernelGGL(gn_stats, dim3(nchunk, p.T), dim3(GN_THREADS), lds, s, p, nchunk, rpc);
     const int fin_threads = ((p.temporal ? p.T : 1) * nchunk > 64) ? 1024 : 256;
     hipLaunchKernelGGL(gn_finalize, dim3(p.T), dim3(fin_threads), 0, s, p, nchunk, ab);
-    hipLaunchKernelGGL(gn_apply, dim3(nchunk, p.T), dim3(GN_THREADS), 0, s, p, rpc, (const float*)ab);
+    launch_gn_apply(p, nchunk, rpc, (const float*)ab, s);
   }
   UG_CHECK(hipGetLastError());
   return false;

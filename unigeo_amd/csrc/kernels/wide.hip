@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_gn32_apply(const Gn32P p, int rpc) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float f = ((e < 4 ? xa[e] : xb[e - 4]) - mean[e]) * ga[e] + be[e];
-      if (p.silu) f = f / (1.0f + __expf(-f));
+      if (p.silu) f = f * __builtin_amdgcn_rcpf(1.0f + __expf(-f));
       const f16 h = (f16)f;
       hi[e] = h; lo[e] = (f16)(f - (float)h);
     }
