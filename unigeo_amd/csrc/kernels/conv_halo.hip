@@ -244,15 +244,15 @@ __global__ __launch_bounds__(12 * 64, 3) void conv_halo_kernel(const GemmP p) {
       __builtin_amdgcn_sched_group_barrier(0x008, Q - R * (Q / R), 0);
       __builtin_amdgcn_sched_group_barrier(0x008, Q, 0);
     }
-    if (tap == 8 && last_chunk) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all fragment reads of this slot / this halo are done before they are handed back
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (tap == 8 && last_chunk) {   // after the barrier: the fetch waves go on with the next tile's steps while the compute waves are in the epilogue (gemm_ws_kernel, round 6)
       int t, y0, x0, n0; tile_origin(tw.first + ti * tw.step, t, y0, x0, n0);
       const int m0 = (t * p.Ho + y0) * p.Wo + x0 - p.m_off;
       if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, (t * tpf + (y0 / TH) * txn + (x0 >> LG)) * (BM / WTM) + wm);
       else tile_epilogue<MT, NT, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, 0);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all fragment reads of this slot / this halo are done before they are handed back
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
   };
   for (ti = 0; ti < my_tiles; ++ti) {
     for (int c = 0; c < nchunks; ++c, ++cp_gc) {

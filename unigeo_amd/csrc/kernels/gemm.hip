@@ -856,6 +856,7 @@ __global__ __launch_bounds__((WMW * WNW + 4) * 64, 3) void gemm_ws_kernel(const 
   constexpr bool PREK = (BM == 192);
   EpiPre<MT, NT> pre;
   const bool do_pre = PREK && p.splitk <= 1 && !(p.tune_knobs & 2097152);
+  const bool lean = !ST && tile_epilogue_lean_ok(p, WTN) && !(p.tune_knobs & 8388608);   // the epilogue without its run-time variants (kernels/gemm_common.h); knob 8388608 = off (A/B)
   const int prow_ks = nk > 3 ? nk - 3 : 0;
   __builtin_amdgcn_s_barrier();          // step 0 published
   asm volatile("" ::: "memory");
@@ -921,19 +922,24 @@ __global__ __launch_bounds__((WMW * WNW + 4) * 64, 3) void gemm_ws_kernel(const 
       }
     }
     UG_STAMP(1);
-    if (++cp_ks == nk) {
-      cp_ks = 0;
-      const int tile = tw.first + (cp_ti++) * tw.step;
-      { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn);
-        if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm);
-        else if (PREK && do_pre) tile_epilogue<MT, NT, WTM, WTN, PREK>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off, &pre);
-        else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
-    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all fragment reads of this slot are done before it is handed back
     UG_STAMP(2);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     UG_STAMP(3);
+    // The epilogue of a tile runs AFTER the barrier that ends its last K step (round 6): the barrier hands the slot back, so the fetch waves issue the next
+    // step's loads and wait for them WHILE the compute waves are in the epilogue - before, they sat at this barrier for the whole epilogue and the fetch
+    // pipeline (what paces the K loop) stood still for it.  The epilogue touches no LDS, and the accumulators are not needed before the next step's MFMAs.
+    if (++cp_ks == nk) {
+      cp_ks = 0;
+      const int tile = tw.first + (cp_ti++) * tw.step;
+      { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn);
+        if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm);
+        else if (lean && PREK && do_pre) tile_epilogue_lean<MT, NT, WTM, WTN, PREK>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off, &pre);
+        else if (lean) tile_epilogue_lean<MT, NT, WTM, WTN, false>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off, nullptr);
+        else if (PREK && do_pre) tile_epilogue<MT, NT, WTM, WTN, PREK>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off, &pre);
+        else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
+    }
 #ifdef UG_GEMM_TRACE
     if (traced && fi == 40) {
       __builtin_amdgcn_s_waitcnt(0);

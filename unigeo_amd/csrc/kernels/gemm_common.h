@@ -2,6 +2,7 @@
 // activation functions, the LDS chunk swizzle, the tile walk and the per-tile epilogue.
 #pragma once
 #include "../common.h"
+#include <type_traits>
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -294,6 +295,87 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][N
       }
     }
   }
+}
+
+// The epilogue of the common case without its run-time variants (round 6): fp16 output, bias / bias2, at most ONE fp16 residual (c0 == 1), no activation, no GEGLU,
+// no split-K, no scatter, 8-aligned leading dimensions, c1 == 1 (so that either contraction of c0 v + c1 r gives the same bits), N a multiple of the wave's column count (every wave is wholly inside or wholly outside N).  tile_epilogue
+// decides all of that per 8-column chunk of every row block with uniform branches - ~110 branches and ~700 VALU instructions per wave and tile, which a
+// short-K tile (K = 640: 240 MFMAs per wave) pays as 20 - 30 % of its time.  Same arithmetic in the same order as tile_epilogue's vector path (c0 * v with
+// c0 == 1 is exact), so the outputs are bit-identical; the launch-uniform test is tile_epilogue_lean_ok.
+__device__ __forceinline__ bool tile_epilogue_lean_ok(const GemmP& p, int wtn) {
+  return p.splitk <= 1 && !(p.flags & (UG_F_GEGLU | UG_F_OUT_F32 | UG_F_R1_F32)) && !p.R2 && p.act == UG_ACT_NONE && p.c0 == 1.0f && !p.halo_tw && !p.up_phase &&
+         (p.ldo & 7) == 0 && (!p.R1 || ((p.ldr1 & 7) == 0 && p.c1 == 1.0f)) && p.N % wtn == 0;
+}
+template <int MT, int NT, int WTM, int WTN, bool PRE>
+__device__ __forceinline__ void tile_epilogue_lean(const GemmP& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wm, int wn, int lane, long out_off,
+                                                   const EpiPre<MT, NT>* pre) {
+  constexpr int WID = 4 * NT;
+  constexpr int CH = (WID % 8 == 0) ? 8 : 4, NV = WID / CH;
+  typedef typename HVec<CH>::type hvec;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int nb = n0 + wn * WTN + g * WID;
+  const bool in = n0 + wn * WTN < p.N;          // uniform per wave (N % WTN == 0)
+  float bv[WID];
+#pragma unroll
+  for (int e = 0; e < WID; ++e) bv[e] = 0.f;
+  if (in) {
+    if (p.bias) {
+#pragma unroll
+      for (int e = 0; e < WID; e += CH) {
+        hvec b;
+        if constexpr (PRE) b = pre->b1[e / CH]; else b = *(const hvec*)(p.bias + nb + e);
+#pragma unroll
+        for (int q = 0; q < CH; ++q) bv[e + q] += (float)b[q];
+      }
+    }
+    if (p.bias2) {
+#pragma unroll
+      for (int e = 0; e < WID; e += CH) {
+        hvec b;
+        if constexpr (PRE) b = pre->b2[e / CH]; else b = *(const hvec*)(p.bias2 + nb + e);
+#pragma unroll
+        for (int q = 0; q < CH; ++q) bv[e + q] += (float)b[q];
+      }
+    }
+  }
+  f16* const Ob = (f16*)p.Out + out_off + nb;
+  auto rows = [&](auto HAS_R1) {
+    constexpr bool R1 = decltype(HAS_R1)::value;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * WTM + i * 16 + l15;
+      const bool ok = in && m < p.M;
+      hvec r[NV];
+      if constexpr (R1 && !PRE) {
+        if (ok) {
+#pragma unroll
+          for (int v = 0; v < NV; ++v) r[v] = *(const hvec*)(p.R1 + (long)m * p.ldr1 + nb + v * CH);
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        float o[CH];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) o[q] = acc[i][(v * CH + q) >> 2][(v * CH + q) & 3] + bv[v * CH + q];
+        if constexpr (R1) {
+          hvec rr;
+          if constexpr (PRE) rr = pre->r1[i][v]; else rr = r[v];
+#pragma unroll
+          for (int q = 0; q < CH; ++q) o[q] += p.c1 * (float)rr[q];
+        }
+        hvec h;
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+          asm("" : "+v"(o[q]));      // keeps the fp32 sum and its fp16 rounding two instructions: hipcc otherwise folds `(f16)fma(c1, r, s)` into ONE v_fma_mixlo_f16
+          h[q] = (f16)o[q];          // (a single rounding - one fp16 ulp away from every other kernel's result in the double-rounding cases; the cross-config test found it)
+        }
+        if (ok) *(hvec*)(Ob + (long)m * p.ldo + v * CH) = h;
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  if (p.R1) rows(std::true_type{}); else rows(std::false_type{});
 }
 
 // sum over the 16 lanes of a DPP row (the lanes that hold the 16 rows of one MFMA block for the same columns): xor 1, xor 2 inside the quads,
