@@ -212,6 +212,7 @@ __global__ __launch_bounds__(12 * 64, 3) void conv_halo_kernel(const GemmP p) {
   const char* Hb = nullptr;
   int ti = 0;
   bool last_chunk = false;
+  const bool lean = !ST && BN != 160 && tile_epilogue_lean_ok(p, WTN, true) && !(p.tune_knobs & 8388608);   // (the 160-column tiles have no register to spare)   // the epilogue without its run-time variants (kernels/gemm_common.h)
   // one K step = one tap of the current chunk; TAP is a compile-time constant (the nine taps are nine instantiations), so dx selects a_pre
   // statically and dy / the row-block offset / the ring slot are immediates
   auto step = [&](auto TAP) {
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(12 * 64, 3) void conv_halo_kernel(const GemmP p) {
       int t, y0, x0, n0; tile_origin(tw.first + ti * tw.step, t, y0, x0, n0);
       const int m0 = (t * p.Ho + y0) * p.Wo + x0 - p.m_off;
       if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, (t * tpf + (y0 / TH) * txn + (x0 >> LG)) * (BM / WTM) + wm);
+      else if constexpr (BN != 160) { if (lean) tile_epilogue_lean<MT, NT, WTM, WTN, false, true>(p, acc, m0, n0, wm, wn, lane, 0, nullptr); else tile_epilogue<MT, NT, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, 0); }
       else tile_epilogue<MT, NT, WTM, WTN>(p, acc, m0, n0, wm, wn, lane, 0);
     }
   };

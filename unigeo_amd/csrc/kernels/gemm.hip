@@ -304,6 +304,9 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
 #pragma unroll
   for (int s0 = 0; s0 < NST - 1; ++s0)
     if (s0 < total_it) issue();
+  // 1: tile_epilogue_lean, 2: tile_epilogue_geglu_lean (64-column wave tiles), 0: tile_epilogue with all its run-time variants (kernels/gemm_common.h; knob 8388608 = always 0)
+  // (the 256 x 256 tiles sit at the 256-register limit: only the GEGLU form - what the clip uses them for - and only in the dense kernels)
+  const int lean_epi = (ST || (p.tune_knobs & 8388608)) ? 0 : (BM * BN < 65536 && tile_epilogue_lean_ok(p, WTN)) ? 1 : (NT == 4 && !CONV && tile_epilogue_geglu_lean_ok(p, WTN)) ? 2 : 0;
   bool drain = false;   // after an epilogue the in-flight count also holds its loads/stores: drain once
   int cp_ti = 0, cp_ks = 0, cp_slot = 0;
 #ifdef UG_GEMM_TRACE
@@ -403,7 +406,13 @@ __global__ __launch_bounds__(WMW * WNW * 64, (GemmOcc<BM, BN, BK, NST, WMW, WNW>
     drain = true;
     const int tile = tw.first + ti * tw.step;
     { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn);
-      if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm); else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
+      if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm);
+      else if constexpr (BM * BN < 65536) {
+        if (lean_epi == 1) tile_epilogue_lean<MT, NT, WTM, WTN, false>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off, nullptr);
+        else if constexpr (NT == 4 && !CONV) { if (lean_epi == 2) tile_epilogue_geglu_lean<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
+        else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off);
+      } else if constexpr (NT == 4 && !CONV) { if (lean_epi == 2) tile_epilogue_geglu_lean<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
+      else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
   }
 }
 
@@ -577,6 +586,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ldr_kernel(const GemmP p) {
     for (int s0 = 0; s0 < NST - 1; ++s0)
       if (s0 < total_it) issue();
   }
+  // 1: tile_epilogue_lean, 2: tile_epilogue_geglu_lean (64-column wave tiles), 0: tile_epilogue with all its run-time variants (kernels/gemm_common.h; knob 8388608 = always 0)
+  // (the 256 x 256 tiles sit at the 256-register limit: only the GEGLU form - what the clip uses them for - and only in the dense kernels)
+  const int lean_epi = (ST || (p.tune_knobs & 8388608)) ? 0 : (BM * BN < 65536 && tile_epilogue_lean_ok(p, WTN)) ? 1 : (NT == 4 && !CONV && tile_epilogue_geglu_lean_ok(p, WTN)) ? 2 : 0;
   bool drain = false;
   int cp_ti = 0, cp_ks = 0, cp_slot = 0;
 #ifdef UG_GEMM_TRACE
@@ -636,7 +648,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ldr_kernel(const GemmP p) {
     const int tile = tw.first + (cp_ti++) * tw.step;
     drain = true;
     { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn);
-      if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm); else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
+      if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm);
+      else if constexpr (BM * BN < 65536) {
+        if (lean_epi == 1) tile_epilogue_lean<MT, NT, WTM, WTN, false>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off, nullptr);
+        else if constexpr (NT == 4 && !CONV) { if (lean_epi == 2) tile_epilogue_geglu_lean<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
+        else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off);
+      } else if constexpr (NT == 4 && !CONV) { if (lean_epi == 2) tile_epilogue_geglu_lean<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
+      else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
   }
 }
 
@@ -857,6 +875,7 @@ __global__ __launch_bounds__((WMW * WNW + 4) * 64, 3) void gemm_ws_kernel(const 
   EpiPre<MT, NT> pre;
   const bool do_pre = PREK && p.splitk <= 1 && !(p.tune_knobs & 2097152);
   const bool lean = !ST && tile_epilogue_lean_ok(p, WTN) && !(p.tune_knobs & 8388608);   // the epilogue without its run-time variants (kernels/gemm_common.h); knob 8388608 = off (A/B)
+  const bool lean_geglu = !ST && NT == 4 && tile_epilogue_geglu_lean_ok(p, WTN) && !(p.tune_knobs & 8388608);
   const int prow_ks = nk > 3 ? nk - 3 : 0;
   __builtin_amdgcn_s_barrier();          // step 0 published
   asm volatile("" ::: "memory");
@@ -935,10 +954,19 @@ __global__ __launch_bounds__((WMW * WNW + 4) * 64, 3) void gemm_ws_kernel(const 
       const int tile = tw.first + (cp_ti++) * tw.step;
       { int etm, etn; tile_coord_p(p, tile, ntm, ntn, etm, etn);
         if constexpr (ST) tile_epilogue_stats<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, etm * WMW + wm);
-        else if (lean && PREK && do_pre) tile_epilogue_lean<MT, NT, WTM, WTN, PREK>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off, &pre);
-        else if (lean) tile_epilogue_lean<MT, NT, WTM, WTN, false>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off, nullptr);
-        else if (PREK && do_pre) tile_epilogue<MT, NT, WTM, WTN, PREK>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off, &pre);
-        else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
+        else if (PREK && do_pre) {      // 192-row tiles: epilogue operands prefetched (EpiPre)
+          if (lean) tile_epilogue_lean<MT, NT, WTM, WTN, PREK>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off, &pre);
+          else if constexpr (NT == 4) { if (lean_geglu) tile_epilogue_geglu_lean<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off);
+            else tile_epilogue<MT, NT, WTM, WTN, PREK>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off, &pre); }
+          else tile_epilogue<MT, NT, WTM, WTN, PREK>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off, &pre);
+        } else if constexpr (PREK) {    // (split-K partial sums, knob 2097152)
+          tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off);
+        } else {
+          if (lean) tile_epilogue_lean<MT, NT, WTM, WTN, false>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off, nullptr);
+          else if constexpr (NT == 4) { if (lean_geglu) tile_epilogue_geglu_lean<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off);
+            else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off); }
+          else tile_epilogue<MT, NT, WTM, WTN>(p, acc, etm * BM, etn * BN, wm, wn, lane, out_off);
+        } }
     }
 #ifdef UG_GEMM_TRACE
     if (traced && fi == 40) {

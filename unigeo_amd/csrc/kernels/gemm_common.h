@@ -302,11 +302,11 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x4 (&acc)[MT][N
 // decides all of that per 8-column chunk of every row block with uniform branches - ~110 branches and ~700 VALU instructions per wave and tile, which a
 // short-K tile (K = 640: 240 MFMAs per wave) pays as 20 - 30 % of its time.  Same arithmetic in the same order as tile_epilogue's vector path (c0 * v with
 // c0 == 1 is exact), so the outputs are bit-identical; the launch-uniform test is tile_epilogue_lean_ok.
-__device__ __forceinline__ bool tile_epilogue_lean_ok(const GemmP& p, int wtn) {
-  return p.splitk <= 1 && !(p.flags & (UG_F_GEGLU | UG_F_OUT_F32 | UG_F_R1_F32)) && !p.R2 && p.act == UG_ACT_NONE && p.c0 == 1.0f && !p.halo_tw && !p.up_phase &&
+__device__ __forceinline__ bool tile_epilogue_lean_ok(const GemmP& p, int wtn, bool halo = false) {
+  return p.splitk <= 1 && !(p.flags & (UG_F_GEGLU | UG_F_OUT_F32 | UG_F_R1_F32)) && !p.R2 && p.act == UG_ACT_NONE && p.c0 == 1.0f && (halo || !p.halo_tw) && !p.up_phase &&
          (p.ldo & 7) == 0 && (!p.R1 || ((p.ldr1 & 7) == 0 && p.c1 == 1.0f)) && p.N % wtn == 0;
 }
-template <int MT, int NT, int WTM, int WTN, bool PRE>
+template <int MT, int NT, int WTM, int WTN, bool PRE, bool HALO = false>   // HALO: the halo convolution's 2-D pixel tile (rows -> pixels as in tile_epilogue)
 __device__ __forceinline__ void tile_epilogue_lean(const GemmP& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wm, int wn, int lane, long out_off,
                                                    const EpiPre<MT, NT>* pre) {
   constexpr int WID = 4 * NT;
@@ -343,7 +343,8 @@ __device__ __forceinline__ void tile_epilogue_lean(const GemmP& p, f32x4 (&acc)[
     constexpr bool R1 = decltype(HAS_R1)::value;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int m = m0 + wm * WTM + i * 16 + l15;
+      int m = m0 + wm * WTM + i * 16 + l15;
+      if constexpr (HALO) { const int rr = wm * WTM + i * 16 + l15; m = m0 + (rr >> p.halo_lg) * p.Wo + (rr & (p.halo_tw - 1)); }
       const bool ok = in && m < p.M;
       hvec r[NV];
       if constexpr (R1 && !PRE) {
@@ -378,6 +379,58 @@ __device__ __forceinline__ void tile_epilogue_lean(const GemmP& p, f32x4 (&acc)[
   if (p.R1) rows(std::true_type{}); else rows(std::false_type{});
 }
 
+// The GEGLU projection's epilogue without its run-time variants (round 6; see tile_epilogue_lean): bias (+ bias2), GEGLU on the lane's 8 (value, gate) pairs, fp16
+// store of 8 outputs per row - tile_epilogue's vector path with c0 == 1 and no residual / activation / fp32 output.
+__device__ __forceinline__ bool tile_epilogue_geglu_lean_ok(const GemmP& p, int wtn) {
+  return p.splitk <= 1 && (p.flags & UG_F_GEGLU) && !(p.flags & (UG_F_OUT_F32 | UG_F_R1_F32)) && !p.R1 && !p.R2 && p.act == UG_ACT_NONE && p.c0 == 1.0f && !p.halo_tw &&
+         !p.up_phase && (p.ldo & 7) == 0 && p.N % wtn == 0;
+}
+template <int MT, int NT, int WTM, int WTN>
+__device__ __forceinline__ void tile_epilogue_geglu_lean(const GemmP& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wm, int wn, int lane, long out_off) {
+  constexpr int WID = 4 * NT;
+  static_assert(WID == 16, "GEGLU: 8 value + 8 gate columns per lane");
+  const int l15 = lane & 15, g = lane >> 4;
+  const int nb = n0 + wn * WTN + g * WID;
+  const bool in = n0 + wn * WTN < p.N;
+  float bv[WID];
+#pragma unroll
+  for (int e = 0; e < WID; ++e) bv[e] = 0.f;
+  if (in) {
+    if (p.bias) {
+#pragma unroll
+      for (int e = 0; e < WID; e += 8) { const f16x8 b = *(const f16x8*)(p.bias + nb + e);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bv[e + q] += (float)b[q]; }
+    }
+    if (p.bias2) {
+#pragma unroll
+      for (int e = 0; e < WID; e += 8) { const f16x8 b = *(const f16x8*)(p.bias2 + nb + e);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bv[e + q] += (float)b[q]; }
+    }
+  }
+  f16* const Ob = (f16*)p.Out + out_off + nb / 2;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wm * WTM + i * 16 + l15;
+    float v[WID];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r] + bv[j * 4 + r];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f16x8 h;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      f32x2 r = geglu2((f32x2){v[e], v[e + 1]}, (f32x2){v[8 + e], v[9 + e]});
+      asm("" : "+v"(r));           // (no fusing of the last multiply with the fp16 rounding: tile_epilogue_lean)
+      h[e] = (f16)r.x; h[e + 1] = (f16)r.y;
+    }
+    if (in && m < p.M) *(f16x8*)(Ob + (long)m * p.ldo) = h;
+  }
+}
+
 // sum over the 16 lanes of a DPP row (the lanes that hold the 16 rows of one MFMA block for the same columns): xor 1, xor 2 inside the quads,
 // then the mirrored half row and the mirrored row - every lane ends up with the total
 __device__ __forceinline__ float row16_sum(float x) {
@@ -402,6 +455,10 @@ __device__ __forceinline__ void tile_epilogue_stats(const GemmP& p, f32x4 (&acc)
   const int l15 = lane & 15, g = lane >> 4;
   const int nb = n0 + wn * WTN + g * WID;
   const bool full = (nb + WID <= p.N);
+  // MODE 0: every run-time variant (second residual, activation, scale factors); 1 / 2 (round 6): the common case - c0 == 1, no activation, no second residual -
+  // with (1) / without (2) the fp16 residual (c1 == 1), decided once per tile instead of per row block and chunk; the same arithmetic, bit-identical outputs
+  auto body = [&](auto MODE_) {
+  constexpr int MODE = decltype(MODE_)::value;
 #pragma unroll
   for (int e = 0; e < WID; e += 8) {
     float bv[8];
@@ -425,30 +482,36 @@ __device__ __forceinline__ void tile_epilogue_stats(const GemmP& p, f32x4 (&acc)
       float o[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        o[q] = p.c0 * (acc[i][(e + q) >> 2][(e + q) & 3] + bv[q]);
+        if constexpr (MODE == 0) o[q] = p.c0 * (acc[i][(e + q) >> 2][(e + q) & 3] + bv[q]);
+        else o[q] = acc[i][(e + q) >> 2][(e + q) & 3] + bv[q];
         acc[i][(e + q) >> 2][(e + q) & 3] = 0.f;
       }
       if (!full) continue;
-      if (p.R1) {
+      if (MODE == 1 || (MODE == 0 && p.R1)) {
         const f16x8 r = *(const f16x8*)(p.R1 + (long)m * p.ldr1 + nb + e);
 #pragma unroll
         for (int q = 0; q < 8; ++q) o[q] += p.c1 * (float)r[q];
       }
-      if (p.R2) {
-        const f16x8 r = *(const f16x8*)(p.R2 + (long)m * p.ldr2 + nb + e);
+      if constexpr (MODE == 0) {
+        if (p.R2) {
+          const f16x8 r = *(const f16x8*)(p.R2 + (long)m * p.ldr2 + nb + e);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] += p.c2 * (float)r[q];
-      }
-      if (p.act == UG_ACT_SILU) {
+          for (int q = 0; q < 8; ++q) o[q] += p.c2 * (float)r[q];
+        }
+        if (p.act == UG_ACT_SILU) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] = silu_f(o[q]);
-      } else if (p.act == UG_ACT_GELU) {
+          for (int q = 0; q < 8; ++q) o[q] = silu_f(o[q]);
+        } else if (p.act == UG_ACT_GELU) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] = gelu_f(o[q]);
+          for (int q = 0; q < 8; ++q) o[q] = gelu_f(o[q]);
+        }
       }
       f16x8 h;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) h[q] = (f16)o[q];
+      for (int q = 0; q < 8; ++q) {
+        if constexpr (MODE != 0) asm("" : "+v"(o[q]));   // (no fusing of the residual add with the fp16 rounding: tile_epilogue_lean)
+        h[q] = (f16)o[q];
+      }
       *(f16x8*)((f16*)p.Out + (long)m * p.ldo + nb + e) = h;
 #pragma unroll
       for (int q = 0; q < 8; ++q) { const float f = (float)h[q]; ssum[q] += f; ssq[q] += f * f; }
@@ -461,4 +524,9 @@ __device__ __forceinline__ void tile_epilogue_stats(const GemmP& p, f32x4 (&acc)
       for (int q = 0; q < 8; q += 2) *(f32x4*)(dst + q) = (f32x4){ssum[q], ssq[q], ssum[q + 1], ssq[q + 1]};
     }
   }
+  };
+  const bool lean = !p.R2 && p.act == UG_ACT_NONE && p.c0 == 1.0f && (!p.R1 || p.c1 == 1.0f) && !(p.tune_knobs & 8388608);
+  if (!lean) body(std::integral_constant<int, 0>{});
+  else if (p.R1) body(std::integral_constant<int, 1>{});
+  else body(std::integral_constant<int, 2>{});
 }
