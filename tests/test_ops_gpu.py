@@ -583,6 +583,48 @@ def test_groupnorm_statistics_from_conv_epilogue(engine, T, H, W, C, O, kt, k, t
     assert (d > 0).mean() < 0.02, f"epilogue vs pass statistics: {(d > 0).mean():.3%} of the elements differ"
 
 
+@pytest.mark.parametrize("cfg", [-1, 0, 3, 14, 15, 19, 35, 54, 59, 61, 62, 63, 64])
+def test_lean_epilogue_forms_equal_the_general_epilogue_bit_for_bit(engine, cfg):
+    """Round 6: every GEMM-family kernel takes a compile-time form of its epilogue for the common cases (tile_epilogue_lean, tile_epilogue_geglu_lean, modes 1 / 2 of
+    the statistics epilogue; kernels/gemm_common.h), chosen per launch from a launch-uniform test.  Knob 8388608 sends every launch through the general epilogue with
+    its run-time variants instead: the outputs must be identical bit for bit - dense with / without bias and residual, GEGLU, ragged M, 3x3 convolutions on the
+    halo-staged kernels with and without the GroupNorm statistics epilogue, a temporal convolution, a stride-2 convolution, and a residual scale c1 != 1 (general form
+    on both sides).  cfg -1 = the planner's tiles (halo kernels, producer / consumer kernels), the others force one tile family each."""
+    rng = np.random.default_rng(900 + cfg)
+    M, K, N = 2049, 1344, 640
+    A, Wd, b, R = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5), rnd(rng, N), rnd(rng, M, N)
+    Rg = rnd(rng, M, N // 2)
+    x = rnd(rng, 3, 48, 64, 128)
+    w3 = rnd(rng, 256, 128, 1, 3, 3, scale=(9 * 128) ** -0.5)
+    wt = rnd(rng, 128, 128, 3, 1, 1, scale=(3 * 128) ** -0.5)
+    b3, bt = rnd(rng, 256), rnd(rng, 128)
+    res = rnd(rng, 3, 48, 64, 256)
+    gamma, beta = h16(1.0 + 0.2 * rng.standard_normal(256)), h16(0.1 * rng.standard_normal(256))
+    geglu_ok = cfg in (-1, 0, 15, 35, 54, 62, 64)
+
+    def run():
+        outs = [engine.op_linear(A, Wd, b, R1=R), engine.op_linear(A, Wd, b), engine.op_linear(A, Wd), engine.op_linear(A, Wd, b, R1=R, c1=0.75),
+                engine.op_conv(x, w3, b3), engine.op_conv(x, wt, bt, kt=3, k=1, pad_t=0, pad_l=0), engine.op_conv(x, w3, b3, stride=2)]
+        if geglu_ok:
+            outs.append(engine.op_linear(A, Wd, b, geglu=True))
+        outs += list(engine.op_conv_gn(x, w3, b3, 32, 1e-5, gamma, beta, res=res)[:3])
+        outs += list(engine.op_conv_gn(x, w3, b3, 32, 1e-5, gamma, beta)[:3])
+        return outs
+    try:
+        _force(engine, cfg)
+        engine.tune_force(-100 - 8388608, 0)
+        ref = run()
+        engine.tune_force(-100, 0)
+        got = run()
+        for i, (g_, r_) in enumerate(zip(got, ref)):
+            assert np.array_equal(g_, r_), f"cfg {cfg} output {i}: lean vs general epilogue, max diff {np.abs(g_ - r_).max()}"
+    finally:
+        engine.tune_force(-100, 0)
+        _force(engine, -1)
+    y = t(A) @ t(Wd).T + t(b) + t(R)
+    assert_close(got[0], y.numpy(), TOL, "dense + bias + residual")
+
+
 @pytest.mark.parametrize("cfg,want_rb", [(14, 64), (19, 128), (35, 128), (54, 64), (59, 128), (63, 96), (64, 48)])
 def test_statistics_epilogue_on_every_instantiated_tile(engine, cfg, want_rb):
     """Every general tile that is instantiated with the statistics epilogue, forced on one temporal convolution (the planner would pick one of them):
