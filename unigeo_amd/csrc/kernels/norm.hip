@@ -704,11 +704,75 @@ __global__ __launch_bounds__(256) void ln_kernel(const LayerNormP p) {
   }
 }
 
+// Round 6: rows of 320 / 640 / 1280 channels (every LayerNorm of the clip) on L = C / 40 lanes each - 8 / 4 / 2 rows per wave, five 16-byte vectors per lane, all
+// 64 lanes loading (ln_kernel's one-wave-per-row form has 40 of 64 lanes active at C = 320 and a half-empty second / third load at 640 / 1280), the two
+// reductions over log2(L) butterfly steps inside the row's lane group.  Same two-pass statistics and the same output expression as ln_kernel; the summation
+// order inside a row differs (results agree to fp32 rounding of mean / variance).  Not for the MX-fp8 output form.
+template <int L>
+__global__ __launch_bounds__(256) void ln40_kernel(const LayerNormP p) {
+  constexpr int RPW = 64 / L, NV = 5;
+  const int lane = threadIdx.x & 63, sub = lane / L, l = lane % L;
+  const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + sub;
+  const bool ok = row < p.M;
+  const int C = 40 * L;
+  const f16* xr = p.X + (ok ? row : 0) * C + l * 8;
+  f16x8 h[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) h[k] = *(const f16x8*)(xr + k * L * 8);
+  if (p.addvec) {
+    const f16* ar = p.addvec + (((ok ? row : 0) + p.row0) / p.rows_per_vec) * C + l * 8;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const f16x8 a = *(const f16x8*)(ar + k * L * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h[k][e] = (f16)((float)h[k][e] + (float)a[e]);
+      if (p.Xout && ok) *(f16x8*)(p.Xout + row * C + (l + k * L) * 8) = h[k];
+    }
+  }
+  float x[NV][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { x[k][e] = (float)h[k][e]; sum += x[k][e]; }
+#pragma unroll
+  for (int o = L / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum * (1.0f / (40 * L));
+  float var = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { x[k][e] -= mean; var += x[k][e] * x[k][e]; }
+#pragma unroll
+  for (int o = L / 2; o > 0; o >>= 1) var += __shfl_xor(var, o);
+  const float rstd = rsqrtf(var * (1.0f / (40 * L)) + p.eps);
+  if (!ok) return;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const f16x8 g = *(const f16x8*)(p.gamma + (l + k * L) * 8);
+    const f16x8 b = *(const f16x8*)(p.beta + (l + k * L) * 8);
+    f16x8 y;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = (f16)(x[k][e] * rstd * (float)g[e] + (float)b[e]);
+    *(f16x8*)(p.Y + row * C + (l + k * L) * 8) = y;
+  }
+}
+
 void launch_layernorm(const LayerNormP& p, hipStream_t s) {
   UG_REQUIRE(p.C % 8 == 0, "LayerNorm C must be a multiple of 8");
   const int vpl = cdiv(p.C / 8, 64);
   UG_REQUIRE(vpl <= 4, "LayerNorm C too large");
   if (p.Y8) UG_REQUIRE(p.C % 128 == 0 && p.S8 && p.ld_s8 >= p.M, "LayerNorm MX-fp8 output needs C % 128 == 0 and a scale buffer");
+  static const bool no40 = getenv("UG_LN_NO40") != nullptr;   // A/B aid
+  if (!p.Y8 && !no40 && (p.C == 320 || p.C == 640 || p.C == 1280)) {
+    const int L = p.C / 40, rows_per_block = 4 * (64 / L);
+    dim3 grid(cdiv(p.M, rows_per_block)), block(256);
+    if (L == 8) hipLaunchKernelGGL(ln40_kernel<8>, grid, block, 0, s, p);
+    else if (L == 16) hipLaunchKernelGGL(ln40_kernel<16>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(ln40_kernel<32>, grid, block, 0, s, p);
+    UG_CHECK(hipGetLastError());
+    return;
+  }
   dim3 grid(cdiv(p.M, 4)), block(256);
   switch (vpl) {
     case 1: hipLaunchKernelGGL(ln_kernel<1>, grid, block, 0, s, p); break;
