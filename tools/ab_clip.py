@@ -15,7 +15,9 @@ eng = pipe.engine
 clip = synthetic_clip(T, H, W)
 nl, na = make_noise(T, H, W, 0)
 eng.set_inputs(DepthCrafter.prepare_input(None, clip), nl, na, np.stack(clip["intrinsics"], 0))
-setter = {"epipre": lambda on: eng.tune_force(-100 - (0 if on else 2097152), 0),     # round 5: epilogue operands prefetched during the K loop (192-row producer / consumer tiles)
+if what.startswith("knob:"):      # generic: on = default, off = the knob mask set (a knob is an OFF / old-rule switch): ab_clip.py knob:16777216
+    _mask = int(what.split(":")[1])
+setter = {"knob:%d" % (_mask if what.startswith("knob:") else 0): (lambda on: eng.tune_force(-100 - (0 if on else _mask), 0)), "epipre": lambda on: eng.tune_force(-100 - (0 if on else 2097152), 0),     # round 5: epilogue operands prefetched during the K loop (192-row producer / consumer tiles)
           "walk": lambda on: eng.tune_force(-100 - (0 if on else 128), 0),           # round 5: XCD-owned tile runs (on) vs the round-strided walk
           "rowmajor": lambda on: eng.tune_force(-100 - (0 if on else 1048576), 0),  # round 5: row-major walk when a tile group fits the XCD's window anyway
           "conv_split": lambda on: eng.tune_force(-100 - (0 if on else 1024), 0), "group": lambda on: eng.tune_force(-100 - (0 if on else 32), 0),

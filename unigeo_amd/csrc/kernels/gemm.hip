@@ -690,9 +690,15 @@ static bool gemm_can_bufa(const GemmP& p, int BK, bool packed) {
 // publishes step i+1 and frees slot i % 3.  Only producers ever have loads in flight in the K loop, so the epilogue's
 // global traffic (consumers) needs no drain logic.  LDS image, W row permutation, MFMA chain order and epilogue are those
 // of gemm_kernel: outputs are bit-identical.
+// ring depth of the producer / consumer kernel: three slots; -DUG_WS_NST4 (experiment, round 6): four on the 192 x 128 tile (4 x 40 KiB = the CU's 160 KiB)
+#ifdef UG_WS_NST4
+constexpr int ws_nst(int bm, int bn) { return (bm == 192 && bn == 128) ? 4 : 3; }
+#else
+constexpr int ws_nst(int, int) { return 3; }
+#endif
 template <int BM, int BN, int WMW, int WNW, bool CONV, bool ST = false>   // ST: GroupNorm statistics of the output from the epilogue (GemmP::stat_part)
 __global__ __launch_bounds__((WMW * WNW + 4) * 64, 3) void gemm_ws_kernel(const GemmP p) {
-  constexpr int NST = 3;
+  constexpr int NST = ws_nst(BM, BN);
   constexpr int BK = 64;
   static_assert(BN % 32 == 0 && (BM == 256 || BM == 192) && NST * (BM + BN) * BK * 2 <= 160 * 1024, "ring of three BM x BN x 64 slots must fit 160 KiB; BM / 32 A pieces per fetch wave");
   static_assert(WMW * WNW == 8, "eight consumer waves (three waves per SIMD with the fetch wave)");
@@ -827,9 +833,9 @@ __global__ __launch_bounds__((WMW * WNW + 4) * 64, 3) void gemm_ws_kernel(const 
       if (++ld_slot == NST) ld_slot = 0;
     };
     // prologue: steps 0 .. NST-2; step 0 must have landed before the first barrier
-    if (total_it > 0) issue();
-    if (total_it > 1) issue();
-    if (total_it > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA + LB) : "memory");
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0) if (s0 < total_it) issue();
+    if (total_it >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (LA + LB)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #ifdef UG_GEMM_TRACE
@@ -981,9 +987,9 @@ template <int BN, int WMW, int WNW, int BM = 256>
 static void launch_ws(const GemmP& p, int batch, hipStream_t s) {
   const int ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
 #ifdef UG_GEMM_TRACE
-  const size_t lds = 3 * (BM + BN) * 64 * sizeof(f16) + 2048;
+  const size_t lds = ws_nst(BM, BN) * (BM + BN) * 64 * sizeof(f16) + 2048;
 #else
-  const size_t lds = 3 * (BM + BN) * 64 * sizeof(f16);
+  const size_t lds = ws_nst(BM, BN) * (BM + BN) * 64 * sizeof(f16);
 #endif
   static bool attr[32] = {};
   bool& at = attr[ug_dev_slot()];
@@ -1293,7 +1299,7 @@ void gemm_plan(const GemmP& p, int batch, int* cfg_out, int* split_out) {
   if (!(p.tune_knobs & 4096) && batch == 1) {
     const bool bufa = gemm_can_bufa(p, 64, true);
     if (!p.conv && geglu && p.M >= 4096 && p.N >= 4096 && p.K >= 512) cfg = bufa ? 35 : 15;              // 19200x5120x640: 129 vs 137 us; 4800x10240x1280: 113 vs 120
-    else if (!p.conv && geglu && p.K <= 384 && p.M < 32768 && p.M >= 4096) cfg = 64;                         // feed-forward tail rows 11264x2560x320: 34.6 vs 41.2
+    else if (!p.conv && geglu && p.K <= 384 && p.M < 32768 && p.M >= 4096) cfg = (p.tune_knobs & 16777216) ? 64 : (bufa ? 35 : 15);   // feed-forward tail rows 11264x2560x320: round 3 192x128 (34.6 vs 41.2); round 6, with the lean GEGLU epilogue, the 256x256 tile: 32.7 vs 37.8 in situ (profiles/r06_gemm_insitu_cfg_sweep.txt; knob 16777216 = the old rule)
     else if (!p.conv && !geglu && cfg == 63 && p.K >= 2048 && p.N <= 1280) cfg = 64;                          // 19200x640x2560: 74 vs 79; 4800x1280x5120: 66 vs 69
     else if (!p.conv && !geglu && p.M >= 50000 && p.K <= 384 && p.N >= 640 && p.N < 2048 && bufa) cfg = 59;  // 76800x960x320 (Q|K|V): 77 vs 85
     else if (!p.conv && !geglu && p.N <= 384 && p.K >= 1024 && p.M > 2048 && p.M <= 16384) cfg = 3;          // tail rows 11264x320x1280: 23.8 vs 28.0
