@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const LayerNormP p) {
 // Round 6: rows of 320 / 640 / 1280 channels (every LayerNorm of the clip) on L = C / 40 lanes each - 8 / 4 / 2 rows per wave, five 16-byte vectors per lane, all
 // 64 lanes loading (ln_kernel's one-wave-per-row form has 40 of 64 lanes active at C = 320 and a half-empty second / third load at 640 / 1280), the two
 // reductions over log2(L) butterfly steps inside the row's lane group.  Same two-pass statistics and the same output expression as ln_kernel; the summation
-// order inside a row differs (results agree to fp32 rounding of mean / variance).  Not for the MX-fp8 output form.
+// order inside a row differs (results agree to fp32 rounding of mean / variance).  Carries ln_kernel's MX-fp8 output form (C % 128 == 0).
 template <int L>
 __global__ __launch_bounds__(256) void ln40_kernel(const LayerNormP p) {
   constexpr int RPW = 64 / L, NV = 5;
@@ -746,15 +746,34 @@ __global__ __launch_bounds__(256) void ln40_kernel(const LayerNormP p) {
 #pragma unroll
   for (int o = L / 2; o > 0; o >>= 1) var += __shfl_xor(var, o);
   const float rstd = rsqrtf(var * (1.0f / (40 * L)) + p.eps);
-  if (!ok) return;
+  // (a row's lanes leave together: the 4-lane block-maximum exchange of the fp8 form never crosses rows)
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
+    if (!ok) continue;
     const f16x8 g = *(const f16x8*)(p.gamma + (l + k * L) * 8);
     const f16x8 b = *(const f16x8*)(p.beta + (l + k * L) * 8);
     f16x8 y;
 #pragma unroll
     for (int e = 0; e < 8; ++e) y[e] = (f16)(x[k][e] * rstd * (float)g[e] + (float)b[e]);
-    *(f16x8*)(p.Y + row * C + (l + k * L) * 8) = y;
+    if (!p.Y8) { *(f16x8*)(p.Y + row * C + (l + k * L) * 8) = y; continue; }
+    // MX-fp8 output (ln_kernel's, kernels/mx8.hip semantics on the fp16-rounded values): vector v = l + k L; the 4 lanes l = 4j .. 4j + 3 hold one 32-element block
+    const int v = l + k * L;
+    float amax = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf((float)y[e]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1));
+    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    int ex = 0;
+    if (amax > 0.f) { (void)frexpf(amax, &ex); ex = ex - 1 - 8; }
+    ex = min(max(ex, -127), 127);
+    const float inv = ldexpf(1.0f, -ex);
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = fminf(fmaxf((float)y[e] * inv, -448.f), 448.f);
+    int p0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], 0, false); p0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], p0, true);
+    int p1 = __builtin_amdgcn_cvt_pk_fp8_f32(t[4], t[5], 0, false); p1 = __builtin_amdgcn_cvt_pk_fp8_f32(t[6], t[7], p1, true);
+    *(uint2*)(p.Y8 + row * C + v * 8) = make_uint2((unsigned)p0, (unsigned)p1);
+    if ((l & 3) == 0) ((unsigned char*)(p.S8 + (long)(v >> 4) * p.ld_s8 + row))[(v & 15) >> 2] = (unsigned char)(ex + 127);
   }
 }
 
@@ -764,7 +783,7 @@ void launch_layernorm(const LayerNormP& p, hipStream_t s) {
   UG_REQUIRE(vpl <= 4, "LayerNorm C too large");
   if (p.Y8) UG_REQUIRE(p.C % 128 == 0 && p.S8 && p.ld_s8 >= p.M, "LayerNorm MX-fp8 output needs C % 128 == 0 and a scale buffer");
   static const bool no40 = getenv("UG_LN_NO40") != nullptr;   // A/B aid
-  if (!p.Y8 && !no40 && (p.C == 320 || p.C == 640 || p.C == 1280)) {
+  if (!no40 && (p.C == 320 || p.C == 640 || p.C == 1280)) {
     const int L = p.C / 40, rows_per_block = 4 * (64 / L);
     dim3 grid(cdiv(p.M, rows_per_block)), block(256);
     if (L == 8) hipLaunchKernelGGL(ln40_kernel<8>, grid, block, 0, s, p);
