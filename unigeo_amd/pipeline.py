@@ -81,7 +81,7 @@ class DepthCrafterPipelineHIP:
     def __call__(self, video, height=None, width=None, num_inference_steps=25, guidance_scale=1.0,
                  window_size=110, noise_aug_strength=0.02, decode_chunk_size=None, output_type="np",
                  overlap=25, track_time=False, noise_latents=None, noise_aug=None, seed=None,
-                 intrinsics=None, with_normals=False):
+                 intrinsics=None, with_normals=False, return_frames=True):
         video = np.asarray(video, dtype=np.float32)
         if video.ndim != 4 or video.shape[-1] != 3:
             raise ValueError("video must be [T,H,W,3] float in [0,1]")
@@ -107,5 +107,6 @@ class DepthCrafterPipelineHIP:
         eng.set_inputs(video, noise_latents, noise_aug, intrinsics)
         # T > window_size: upstream DepthCrafter's latent sliding windows (off on the reference path, which passes window_size = T)
         eng.run(num_inference_steps, chunk, with_normals=with_normals, window=window_size if T > window_size else 0, overlap=overlap)
-        frames, depth, normals = eng.get_outputs(frames=True, depth=True, normals=with_normals)
+        # return_frames=False (the plugin's forward, which consumes depth / normals only): the decoded frames stay in HBM - 59 MB less to download per clip
+        frames, depth, normals = eng.get_outputs(frames=bool(return_frames), depth=True, normals=with_normals)
         return SimpleNamespace(frames=[frames], depth=depth, normals=normals)
