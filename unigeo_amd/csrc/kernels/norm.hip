@@ -416,16 +416,27 @@ __global__ __launch_bounds__(NT) void gn_slab(const GroupNormP p) {
 #pragma unroll
   for (int k = 0; k < VMAX; ++k)
     x[k] = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rX, act ? (int)(voff + k * stepx) : (int)OOB, 0, 0));
+  const f16x4 ga = *(const f16x4*)(p.gamma + (act ? c : 0)), be = *(const f16x4*)(p.beta + (act ? c : 0));   // with the slab loads, not behind the reductions (MODE 1 never uses them)
   float mean, rstd;
   const double n = (double)R * cpg;
   if (MODE == 2) {
     // pooled statistics of group g from the T per-frame (mean, M2) partials; uniform addresses, every thread the same arithmetic
+    // (round 6: lane t of every wave loads frame t's partial - one memory round trip instead of T dependent scalar loads - and the sums run over the lanes in
+    // frame order, the same order and the same arithmetic as before; T <= 64 is checked by the launcher, else the serial form)
     const float2* part = (const float2*)p.ws + g;
-    double msum = 0.0;
-    for (int t = 0; t < p.T; ++t) msum += (double)part[(long)t * p.G].x;
-    const double pm = msum / p.T;
-    double m2 = 0.0;
-    for (int t = 0; t < p.T; ++t) { const float2 v = part[(long)t * p.G]; const double d = (double)v.x - pm; m2 += (double)v.y + n * d * d; }
+    double msum = 0.0, m2 = 0.0, pm;
+    if (p.T <= 64) {
+      const int ln = tid & 63;
+      const float2 mine = part[(long)min(ln, p.T - 1) * p.G];
+      auto lane_f = [](float v, int t) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), t)); };   // uniform t: v_readlane
+      for (int t = 0; t < p.T; ++t) msum += (double)lane_f(mine.x, t);
+      pm = msum / p.T;
+      for (int t = 0; t < p.T; ++t) { const double d = (double)lane_f(mine.x, t) - pm; m2 += (double)lane_f(mine.y, t) + n * d * d; }
+    } else {
+      for (int t = 0; t < p.T; ++t) msum += (double)part[(long)t * p.G].x;
+      pm = msum / p.T;
+      for (int t = 0; t < p.T; ++t) { const float2 v = part[(long)t * p.G]; const double d = (double)v.x - pm; m2 += (double)v.y + n * d * d; }
+    }
     mean = (float)pm;
     rstd = (float)(1.0 / sqrt(m2 / (n * p.T) + (double)p.eps));
   } else {
@@ -454,7 +465,6 @@ __global__ __launch_bounds__(NT) void gn_slab(const GroupNormP p) {
 #pragma unroll
     for (int k = 0; k < VMAX; ++k) asm volatile("" : "+v"(x[k]));
   }
-  const f16x4 ga = *(const f16x4*)(p.gamma + (act ? c : 0)), be = *(const f16x4*)(p.beta + (act ? c : 0));
   float a[4], b[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) { a[e] = rstd * (float)ga[e]; b[e] = (float)be[e] - mean * a[e]; }
@@ -716,9 +726,12 @@ __global__ __launch_bounds__(256) void ln40_kernel(const LayerNormP p) {
   const bool ok = row < p.M;
   const int C = 40 * L;
   const f16* xr = p.X + (ok ? row : 0) * C + l * 8;
-  f16x8 h[NV];
+  f16x8 h[NV], gm[NV], bt[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) h[k] = *(const f16x8*)(xr + k * L * 8);
+  // gamma / beta with the row loads, not behind the two reductions: one memory round trip per wave instead of two
+#pragma unroll
+  for (int k = 0; k < NV; ++k) { gm[k] = *(const f16x8*)(p.gamma + (l + k * L) * 8); bt[k] = *(const f16x8*)(p.beta + (l + k * L) * 8); }
   if (p.addvec) {
     const f16* ar = p.addvec + (((ok ? row : 0) + p.row0) / p.rows_per_vec) * C + l * 8;
 #pragma unroll
@@ -750,8 +763,7 @@ __global__ __launch_bounds__(256) void ln40_kernel(const LayerNormP p) {
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     if (!ok) continue;
-    const f16x8 g = *(const f16x8*)(p.gamma + (l + k * L) * 8);
-    const f16x8 b = *(const f16x8*)(p.beta + (l + k * L) * 8);
+    const f16x8 g = gm[k], b = bt[k];
     f16x8 y;
 #pragma unroll
     for (int e = 0; e < 8; ++e) y[e] = (f16)(x[k][e] * rstd * (float)g[e] + (float)b[e]);
